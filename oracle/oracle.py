@@ -1,0 +1,175 @@
+"""ctypes binding of the CPU oracle (oracle/libnf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the shipped neutfem_amd package.
+The method names mirror the reference's Python surface (src/wrapper.cpp:336-1065)
+so parity tests read like the reference's own drivers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile oracle/libnf_oracle.so with gcc (plain C, no GPU needed)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libnf_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libnf_oracle.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "nf_oracle.c")):
+            build()
+        L = C.CDLL(path)
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.nfo_create.restype = vp
+        L.nfo_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp]
+        L.nfo_destroy.argtypes = [vp]
+        L.nfo_info.restype = C.c_long
+        L.nfo_info.argtypes = [vp, C.c_char_p]
+        L.nfo_array.restype = dp
+        L.nfo_array.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
+        L.nfo_set_bc.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+        L.nfo_set_tol.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.nfo_set_linear_solver.argtypes = [vp, C.c_int]
+        L.nfo_reset_flux.argtypes = [vp]
+        L.nfo_set_refactor_each_solve.argtypes = [vp, C.c_int]
+        L.nfo_local_matrices.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp]
+        L.nfo_global_J_indices.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip]
+        L.nfo_global_phi_indices.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip]
+        L.nfo_build.restype = C.c_int
+        L.nfo_build.argtypes = [vp]
+        L.nfo_schur_apply.argtypes = [vp, C.c_int, dp, dp]
+        L.nfo_solve_group.restype = C.c_int
+        L.nfo_solve_group.argtypes = [vp, C.c_int, dp, dp, dp]
+        L.nfo_solve_keff.restype = C.c_double
+        L.nfo_solve_keff.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int]
+        L.nfo_solve_coarse.restype = C.c_double
+        L.nfo_solve_coarse.argtypes = [vp, ip, C.c_int, dp]
+        L.nfo_diag_cache.restype = dp
+        L.nfo_diag_cache.argtypes = [vp, C.c_int]
+        L.nfo_last_keff.restype = C.c_double
+        L.nfo_last_keff.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleNeutFEM:
+    """CPU restatement with the reference's method names (NeutFEM class, src/wrapper.cpp:274)."""
+
+    def __init__(self, rt_order, p_order, ng, x_breaks, y_breaks, z_breaks):
+        L = lib()
+        xb = np.ascontiguousarray(x_breaks, dtype=np.float64)
+        yb = np.ascontiguousarray(y_breaks, dtype=np.float64)
+        zb = np.ascontiguousarray(z_breaks, dtype=np.float64)
+        self._h = L.nfo_create(rt_order, p_order, ng, len(xb), _dp(xb), len(yb), _dp(yb), len(zb), _dp(zb))
+        self._L = L
+        for key in ("dim", "nx", "ny", "nz", "ne", "ng", "k", "m", "nf", "ni", "nloc", "nJloc", "n_phi", "n_J"):
+            setattr(self, key, L.nfo_info(self._h, key.encode()))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.nfo_destroy(self._h)
+            self._h = None
+
+    def info(self, key):
+        return self._L.nfo_info(self._h, key.encode())
+
+    def _arr(self, name, shape=None):
+        n = C.c_long()
+        p = self._L.nfo_array(self._h, name.encode(), C.byref(n))
+        a = np.ctypeslib.as_array(p, shape=(n.value,)) if n.value else np.zeros(0)
+        return a.reshape(shape) if shape is not None else a
+
+    def _cellshape(self, lead):
+        s = list(lead)
+        if self.dim >= 3:
+            s.append(self.nz)
+        if self.dim >= 2:
+            s.append(self.ny)
+        s.append(self.nx)
+        return tuple(s)
+
+    # accessors: views (ng,[nz],[ny],nx), src/NeutFEM.cpp:2626-2730
+    def get_D(self): return self._arr("D", self._cellshape([self.ng]))
+    def get_SigR(self): return self._arr("SigR", self._cellshape([self.ng]))
+    def get_NSF(self): return self._arr("NSF", self._cellshape([self.ng]))
+    def get_KSF(self): return self._arr("KSF", self._cellshape([self.ng]))
+    def get_Chi(self): return self._arr("Chi", self._cellshape([self.ng]))
+    def get_SRC(self): return self._arr("SRC", self._cellshape([self.ng]))
+    def get_SigS(self): return self._arr("SigS", self._cellshape([self.ng, self.ng]))
+
+    def get_flux(self):
+        phi = self._arr("phi").reshape(self.ng, self.ne, self.nloc)[:, :, 0]
+        return np.ascontiguousarray(phi).reshape(self._cellshape([self.ng]))
+
+    def phi_dofs(self): return self._arr("phi").reshape(self.ng, self.n_phi)
+    def J_dofs(self): return self._arr("J").reshape(self.ng, self.n_J)
+
+    def set_bc(self, attr, bctype, value=0.0): self._L.nfo_set_bc(self._h, int(attr), int(bctype), value)
+    def set_tol(self, tk, tf, tl, mo, mi): self._L.nfo_set_tol(self._h, tk, tf, tl, mo, mi)
+    def set_linear_solver(self, t): self._L.nfo_set_linear_solver(self._h, int(t))
+    def reset_flux(self): self._L.nfo_reset_flux(self._h)
+    def set_refactor_each_solve(self, on): self._L.nfo_set_refactor_each_solve(self._h, int(on))
+
+    def BuildMatrices(self):
+        rc = self._L.nfo_build(self._h)
+        if rc:
+            raise RuntimeError(f"oracle build failed ({rc})")
+
+    def SolveKeff(self, use_coarse_init=False, coarse_factors=(), use_diagonal_solver=False, use_cmfd=False):
+        if use_cmfd:
+            raise NotImplementedError("CMFD is out of scope (SURVEY 8f-3)")
+        f = np.asarray(list(coarse_factors), dtype=np.int32)
+        return self._L.nfo_solve_keff(self._h, int(use_coarse_init), f.ctypes.data_as(C.POINTER(C.c_int)), len(f),
+                                      int(use_diagonal_solver))
+
+    def SolveCoarse(self, refine):
+        f = np.asarray(list(refine), dtype=np.int32)
+        out = np.zeros(self.ng * self.n_phi)
+        k = self._L.nfo_solve_coarse(self._h, f.ctypes.data_as(C.POINTER(C.c_int)), len(f), _dp(out))
+        return k, out
+
+    def GetLastKeff(self): return self._L.nfo_last_keff(self._h)
+
+    # oracle-only probes
+    def local_matrices(self, e, D, Sigma):
+        A = np.zeros((self.nJloc, self.nJloc)); B = np.zeros((self.nloc, self.nJloc)); Cm = np.zeros((self.nloc, self.nloc))
+        self._L.nfo_local_matrices(self._h, e, D, Sigma, _dp(A), _dp(B), _dp(Cm))
+        return A, B, Cm
+
+    def global_J_indices(self, ix, iy, iz):
+        idx = np.zeros(self.nJloc, dtype=np.int32)
+        self._L.nfo_global_J_indices(self._h, ix, iy, iz, idx.ctypes.data_as(C.POINTER(C.c_int)))
+        return idx
+
+    def schur_apply(self, g, x):
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.zeros_like(x)
+        self._L.nfo_schur_apply(self._h, g, _dp(x), _dp(y))
+        return y
+
+    def solve_group(self, g, rhs):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        phi = np.zeros(self.n_phi); J = np.zeros(self.n_J)
+        its = self._L.nfo_solve_group(self._h, g, _dp(rhs), _dp(phi), _dp(J))
+        return phi, J, its
+
+    def diag_cache(self, g):
+        p = self._L.nfo_diag_cache(self._h, g)
+        return np.ctypeslib.as_array(p, shape=(self.ne,)).copy()
+
+    def history(self):
+        n = self.info("last_outer")
+        return dict(n_outer=n, k=self._arr("hist_k").copy(), dk=self._arr("hist_dk").copy(),
+                    dphi=self._arr("hist_dphi").copy(), cg=self._arr("hist_cg").copy().reshape(n, self.ng),
+                    coarse_outer=self.info("coarse_outer"))
