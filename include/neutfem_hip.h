@@ -1,0 +1,126 @@
+/*
+ * neutfem_hip.h -- C ABI of the MI355X (gfx950) hot path of neutfem_amd.
+ *
+ * This is the drop-in boundary: plain C types, opaque handle, int status
+ * (0 = ok, <0 = error; text via nf_last_error()).  No exceptions, no torch or
+ * Eigen types cross it.  Each entry point cites the reference interface it
+ * replaces (paths relative to the reference repository jujuC31/NeutFEM).
+ * Host pointers are marked _host, device pointers _dev (fp64 everywhere).
+ *
+ * Layouts (identical to the reference's flat arrays, include/NeutFEM.hpp:365-388):
+ *   cell e = iz*nx*ny + iy*nx + ix                       (src/FEM.cpp:89-91)
+ *   XS      [g*N + e]            SigS [(g_to*ng + g_from)*N + e]
+ *   phi     [g*n_phi + e*n_loc + l]                      (n_loc = 1 for P0)
+ *   J       [g*n_J + f]   faces x | y | z | bubbles      (src/FEM.cpp:264-334)
+ */
+#ifndef NEUTFEM_HIP_H
+#define NEUTFEM_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nf_solver *nf_handle;
+
+enum { NF_OK = 0, NF_ERR_ARG = -1, NF_ERR_NO_DEVICE = -2, NF_ERR_HIP = -3, NF_ERR_UNSUPPORTED = -4,
+       NF_ERR_STATE = -5, NF_ERR_NUMERIC = -6 };
+/* BCType, include/NeutFEM.hpp:51-57 */
+enum { NF_BC_DIRICHLET = 0, NF_BC_NEUMANN = 1, NF_BC_MIRROR = 2, NF_BC_ROBIN = 3, NF_BC_PERIODIC = 4 };
+
+const char *nf_last_error(void);
+/* number of visible HIP devices (0 when there is none); never throws */
+int nf_device_count(void);
+
+/* NeutFEM::NeutFEM (src/NeutFEM.cpp:82-300) + CartesianMesh (src/FEM.cpp:23-83) + FESpace
+ * (src/FEM.cpp:177-259): mesh from break arrays (a 1-entry y/z array = inactive dimension),
+ * RT/P orders clamped like the reference, device = HIP ordinal. */
+int nf_create(int rt_order, int p_order, int ng,
+              int nxb, const double *xb_host, int nyb, const double *yb_host, int nzb, const double *zb_host,
+              int device, nf_handle *out);
+int nf_destroy(nf_handle h);
+
+/* sizes: "dim","nx","ny","nz","ne","ng","n_phi","n_J","n_loc","last_outer","last_cg_total",
+ * "coarse_outer","device" ; returns -1 for an unknown key */
+long nf_info(nf_handle h, const char *key);
+
+/* NeutFEM::SetBC (src/NeutFEM.cpp:337-345): attr per BoundaryID (include/NeutFEM.hpp:73-91).
+ * Only DIRICHLET changes the operator (src/NeutFEM.cpp:1328-1456); the rest is natural/ignored. */
+int nf_set_bc(nf_handle h, int attr, int bc_type);
+
+/* Public XS members D_data_, SigR_data_, NSF_data_, Chi_data_, SigS_data_
+ * (include/NeutFEM.hpp:373-388) -> device.  Host arrays in the reference layouts. */
+int nf_upload_xs(nf_handle h, const double *D_host, const double *SigR_host, const double *NSF_host,
+                 const double *Chi_host, const double *SigS_host);
+
+/* NeutFEM::BuildMatrices (src/NeutFEM.cpp:402-457): AssembleA/B/C, ApplyDirichletToA,
+ * AssembleFissionMatrix, AssembleScatteringMatrix as closed-form per-cell coefficients, plus the
+ * factorisation SchurSolver::SetMatrices does per solve (A_lu_solver_.compute, src/solvers.cpp:163),
+ * done ONCE here as per-grid-line LDL^T.  Invalidates the diagonal cache, keeps the warm start. */
+int nf_build(nf_handle h);
+
+/* SchurSolver::SchurProduct (src/solvers.cpp:535-547): y = C_g x + B A_g^-1 B^T x. */
+int nf_schur_apply(nf_handle h, int g, const double *x_dev, double *y_dev);
+
+/* SchurSolver::SolveSchurImplicit (src/solvers.cpp:577-636): CG from x0 = 0, stop when
+ * ||r||^2 < tol^2 ||b||^2 or after maxit iterations. its/res may be NULL. */
+int nf_solve_group(nf_handle h, int g, const double *rhs_dev, double *phi_dev, double tol, int maxit,
+                   int *its, double *res);
+
+/* NeutFEM::BuildDiagonalSchurCache (src/NeutFEM.cpp:483-597); S_inv for group g is copied to
+ * sinv_host (N doubles) when not NULL. */
+int nf_build_diagonal_cache(nf_handle h);
+int nf_get_diagonal_cache(nf_handle h, int g, double *sinv_host);
+
+typedef struct nf_keff_opts {
+    double tol_keff, tol_flux;      /* NeutFEM::SetTolerance, src/NeutFEM.cpp:327-335 */
+    int max_outer, max_inner;
+    int use_coarse_init;            /* SolveKeff arguments, src/wrapper.cpp:598-603 */
+    int coarse_factors[3];
+    int n_coarse_factors;
+    int use_diagonal_solver;
+    int solver_type;                /* LinearSolverType 0..9 (include/solvers.hpp:176-190) */
+    int solver_type_pushed;         /* 0: set_linear_solver never called -> DIRECT_LU */
+    int profile;                    /* 1: bracket every Schur-apply pass with HIP events */
+} nf_keff_opts;
+
+/* NeutFEM::SolveKeff(bool, vector<int>, bool, bool) (src/NeutFEM.cpp:1627-1815) incl. SolveCoarse
+ * (src/NeutFEM.cpp:2380-2611), ChebyshevAccel (src/solvers.cpp:664-756) and SolveGroupInternal
+ * (src/NeutFEM.cpp:2084-2105).  State kept between calls exactly like the reference:
+ * current flux (nf_set_phi/nf_get_phi) and has_valid_keff_/last_keff_direct_. */
+int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_outer);
+
+/* NeutFEM::SolveCoarse (src/NeutFEM.cpp:2380-2611): returns k_coarse and the prolonged flux
+ * (ng*n_phi doubles, host) without touching the fine solution. */
+int nf_solve_coarse(nf_handle h, const nf_keff_opts *opts, double *k_coarse, double *phi_host);
+
+/* Sol_Phi_ / Sol_J_ (include/NeutFEM.hpp:380-388) and NeutFEM::ResetFlux (src/NeutFEM.cpp:347-354) */
+int nf_set_phi(nf_handle h, const double *phi_host);
+int nf_get_phi(nf_handle h, double *phi_host);
+int nf_get_J(nf_handle h, double *J_host);
+int nf_reset_flux(nf_handle h);
+int nf_set_warm_state(nf_handle h, int has_valid_keff, double last_keff);
+int nf_get_warm_state(nf_handle h, int *has_valid_keff, double *last_keff);
+
+/* per-outer history of the last nf_solve_keff: k, dk, dphi (n_outer each), cg (n_outer*ng) */
+int nf_get_history(nf_handle h, double *k, double *dk, double *dphi, int *cg, int cap_outer);
+
+/* profiling: kernels timed with HIP events on the solver's stream (opts.profile / nf_time_schur_apply).
+ * name in {"schur_x","schur_y","schur_z","schur_apply"}: number of timed launches and their total ms. */
+int nf_profile_get(nf_handle h, const char *name, long *count, double *total_ms);
+int nf_profile_reset(nf_handle h);
+/* times `reps` back-to-back Schur applies on group g (random x) with HIP events; average ms per apply */
+int nf_time_schur_apply(nf_handle h, int g, int reps, double *avg_ms);
+
+/* raw device-memory helpers so callers without torch can drive the *_dev entry points */
+int nf_dev_alloc(nf_handle h, size_t bytes, void **ptr_dev);
+int nf_dev_free(nf_handle h, void *ptr_dev);
+int nf_memcpy_h2d(nf_handle h, void *dst_dev, const void *src_host, size_t bytes);
+int nf_memcpy_d2h(nf_handle h, void *dst_host, const void *src_dev, size_t bytes);
+int nf_synchronize(nf_handle h);
+/* the hipStream_t every kernel of this handle is launched on */
+void *nf_stream(nf_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

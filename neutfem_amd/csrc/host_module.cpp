@@ -1,0 +1,296 @@
+// host_module.cpp -- pybind11 module `neutfem._neutfem_eigen`: the reference's Python surface
+// (src/wrapper.cpp:20-1066) re-exported name for name over the MI355X C ABI (include/neutfem_hip.h).
+//
+// The class keeps what the reference keeps on the host -- cross-section arrays, flux, tolerances,
+// BC map, warm-start flags -- and hands the hot path (BuildMatrices, SolveKeff, SolveCoarse,
+// build_diagonal_cache) to the HIP library.  There is NO CPU fallback: without a HIP device those
+// methods raise RuntimeError.  Methods the reference binds but that lie outside the accelerated
+// path (adjoint, CMFD, VTK, never-defined projections) raise RuntimeError with that explanation.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/neutfem_hip.h"
+
+namespace py = pybind11;
+
+// include/NeutFEM.hpp:51-91, include/solvers.hpp:176-190
+enum class BCType { DIRICHLET, NEUMANN, MIRROR, ROBIN, PERIODIC };
+enum class VerbosityLevel { SILENT = 0, LIGHT = 1, NORMAL = 2, VERBOSE = 3, DEBUG = 4 };
+enum class BoundaryID { LEFT_1D = 1, RIGHT_1D = 2, LEFT_2D = 1, RIGHT_2D = 2, TOP_2D = 3, BOTTOM_2D = 4,
+                        BACK_3D = 1, FRONT_3D = 2, LEFT_3D = 3, RIGHT_3D = 4, TOP_3D = 5, BOTTOM_3D = 6 };
+enum class LinearSolverType { DIRECT_LU, DIRECT_LDLT, DIRECT_LLT, CG, CG_DIAG, CG_ICHOL, BICGSTAB, BICGSTAB_DIAG, BICGSTAB_ILU, LCG };
+
+using arr_t = py::array_t<double, py::array::c_style | py::array::forcecast>;
+
+class NeutFEM {
+public:
+    NeutFEM(int order, int ng, arr_t xb, arr_t yb, arr_t zb) : NeutFEM(order, order, ng, xb, yb, zb) {}
+    NeutFEM(int rt_order, int p_order, int ng, arr_t xb, arr_t yb, arr_t zb)
+    {
+        if (xb.ndim() != 1 || yb.ndim() != 1 || zb.ndim() != 1) throw std::runtime_error("breaks must be 1-D arrays");
+        xb_.assign(xb.data(), xb.data() + xb.size()); yb_.assign(yb.data(), yb.data() + yb.size()); zb_.assign(zb.data(), zb.data() + zb.size());
+        if (xb_.size() < 2) throw std::runtime_error("x_breaks needs at least 2 entries");
+        nx_ = (int)xb_.size() - 1; ny_ = yb_.size() > 1 ? (int)yb_.size() - 1 : 1; nz_ = zb_.size() > 1 ? (int)zb_.size() - 1 : 1;
+        dim_ = nz_ > 1 ? 3 : (ny_ > 1 ? 2 : 1);
+        ng_ = ng; rt_ = std::min(rt_order, 2); p_ = std::min(p_order, 2);
+        if (rt_ < p_) {                                           // src/NeutFEM.cpp:149-169
+            Log(VerbosityLevel::NORMAL, "");
+            Log(VerbosityLevel::NORMAL, "!!! ERREUR: RT" + std::to_string(rt_) + "-P" + std::to_string(p_) + " est instable !!!");
+            Log(VerbosityLevel::NORMAL, "    Pour la stabilite inf-sup, il faut k_RT >= k_P");
+            Log(VerbosityLevel::NORMAL, "    Combinaisons valides: RT0-P0, RT1-P0, RT1-P1, RT2-P0, RT2-P1, RT2-P2");
+            Log(VerbosityLevel::NORMAL, "    Forçage à RT" + std::to_string(rt_) + "-P" + std::to_string(rt_));
+            Log(VerbosityLevel::NORMAL, "");
+            p_ = rt_;
+        }
+        const int k = rt_, m = p_;                                // src/FEM.cpp:177-259
+        nloc_ = dim_ == 1 ? m + 1 : dim_ == 2 ? (m + 1) * (m + 1) : (m + 1) * (m + 1) * (m + 1);
+        const int nf = dim_ == 1 ? 1 : dim_ == 2 ? k + 1 : (k + 1) * (k + 1);
+        const int ni = dim_ == 1 ? k : dim_ == 2 ? k * (k + 1) : k * (k + 1) * (k + 1);
+        ne_ = (long)nx_ * ny_ * nz_; nphi_ = ne_ * nloc_;
+        long njx = (long)(nx_ + 1) * ny_ * nz_ * nf, njy = dim_ >= 2 ? (long)nx_ * (ny_ + 1) * nz_ * nf : 0,
+             njz = dim_ == 3 ? (long)nx_ * ny_ * (nz_ + 1) * nf : 0;
+        nJface_ = njx + njy + njz; nJ_ = nJface_ + ne_ * dim_ * ni;
+        D_.assign(ng * ne_, 1.0); SRC_.assign(ng * ne_, 0.0); SigR_.assign(ng * ne_, 0.01); NSF_.assign(ng * ne_, 0.0);
+        KSF_.assign(ng * ne_, 0.0); Chi_.assign(ng * ne_, 0.0); SigS_.assign((size_t)ng * ng * ne_, 0.0);
+        if (ng > 0) std::fill(Chi_.begin(), Chi_.begin() + ne_, 1.0);
+        Phi_.assign(ng * nphi_, 1.0); PhiAdj_.assign(ng * nphi_, 1.0);
+        const std::string o = "RT" + std::to_string(rt_) + "-P" + std::to_string(p_);
+        Log(VerbosityLevel::NORMAL, "========================================");
+        Log(VerbosityLevel::NORMAL, "  NeutFEM - Solveur " + o + " (MI355X / HIP)");
+        Log(VerbosityLevel::NORMAL, "========================================");
+        Log(VerbosityLevel::NORMAL, "  Dimension     : " + std::to_string(dim_) + "D");
+        Log(VerbosityLevel::NORMAL, "  Maillage      : " + std::to_string(nx_) + " x " + std::to_string(ny_) + " x " + std::to_string(nz_));
+        Log(VerbosityLevel::NORMAL, "  Elements      : " + std::to_string(ne_));
+        Log(VerbosityLevel::NORMAL, "  Groupes       : " + std::to_string(ng));
+        Log(VerbosityLevel::NORMAL, "  DOFs flux     : " + std::to_string(nphi_) + " par groupe");
+        Log(VerbosityLevel::NORMAL, "  DOFs courant  : " + std::to_string(nJ_) + " par groupe");
+        Log(VerbosityLevel::NORMAL, "    - Face DOFs   : " + std::to_string(nJface_));
+        Log(VerbosityLevel::NORMAL, "    - Interior DOFs: " + std::to_string(nJ_ - nJface_));
+        Log(VerbosityLevel::NORMAL, "========================================\n");
+    }
+    ~NeutFEM() { if (h_) nf_destroy(h_); }
+    NeutFEM(const NeutFEM &) = delete;
+
+    // ---- configuration (src/NeutFEM.cpp:306-362) ------------------------------------------------
+    void SetBC(int attr, BCType t, double v) { bc_types_[attr] = t; bc_values_[attr] = v; if (h_ && attr >= 0 && attr < 8) nf_set_bc(h_, attr, (int)t); }
+    void SetRobin(int attr, double a, double b) { robin_[attr] = {a, b}; }
+    void SetLinearSolver(LinearSolverType t) { solver_ = t; solver_pushed_ = true; }
+    void SetTolerance(double tk, double tf, double tl, int mo, int mi) { tol_keff_ = tk; tol_flux_ = tf; tol_L2_ = tl; max_outer_ = mo; max_inner_ = mi; }
+    void SetVerbosity(VerbosityLevel v) { verb_ = v; }
+    void SetCMFDRelaxation(double w) { cmfd_omega_ = w; }
+    void ApplyQuarterSymmetry(int, int) { SetBC(1, BCType::MIRROR, 0.0); SetBC(4, BCType::MIRROR, 0.0); }   // :356-362
+    int AddReflector(py::array_t<double>, py::array_t<double>, py::array_t<double>) { return 0; }           // :2614-2620
+    void SetReflector(int, int, bool) {}
+    void ClearReflectors() {}
+    void ResetFlux()
+    {
+        std::fill(Phi_.begin(), Phi_.end(), 1.0); std::fill(PhiAdj_.begin(), PhiAdj_.end(), 1.0);
+        has_valid_keff_ = false;
+        if (h_) nf_reset_flux(h_);
+    }
+    std::string GetSolverName() const
+    {
+        static const char *n[] = { "SparseLU", "SimplicialLDLT", "SimplicialLLT", "CG", "CG + Diag", "CG + IChol", "BiCGSTAB", "BiCGSTAB + Diag", "BiCGSTAB + ILU", "LSCG" };
+        int i = (int)solver_; return i >= 0 && i < 10 ? n[i] : "Unknown";
+    }
+
+    // ---- hot path ---------------------------------------------------------------------------------
+    void BuildMatrices()
+    {
+        Log(VerbosityLevel::NORMAL, "Assemblage des matrices...");
+        ensure_handle();
+        for (auto &kv : bc_types_) if (kv.first >= 0 && kv.first < 8) chk(nf_set_bc(h_, kv.first, (int)kv.second));
+        chk(nf_upload_xs(h_, D_.data(), SigR_.data(), NSF_.data(), Chi_.data(), SigS_.data()));
+        chk(nf_build(h_));
+        Log(VerbosityLevel::NORMAL, "  Assemblage termine (coefficients + factorisation par lignes sur GPU)");
+    }
+    nf_keff_opts make_opts(bool use_coarse, const std::vector<int> &f, bool use_diag) const
+    {
+        nf_keff_opts o{}; o.tol_keff = tol_keff_; o.tol_flux = tol_flux_; o.max_outer = max_outer_; o.max_inner = max_inner_;
+        o.use_coarse_init = use_coarse && !f.empty();
+        o.n_coarse_factors = (int)std::min<size_t>(f.size(), 3);
+        for (int i = 0; i < o.n_coarse_factors; ++i) o.coarse_factors[i] = f[i];
+        o.use_diagonal_solver = use_diag; o.solver_type = (int)solver_; o.solver_type_pushed = solver_pushed_; o.profile = 0;
+        return o;
+    }
+    double SolveKeff(bool use_coarse_init, const std::vector<int> &coarse_factors, bool use_diagonal_solver, bool use_cmfd)
+    {
+        if (use_cmfd) throw std::runtime_error("use_cmfd=True: CMFD acceleration is outside the accelerated hot path of neutfem_amd (reference: src/NeutFEM.cpp:662-1017)");
+        need_built("SolveKeff");
+        Log(VerbosityLevel::NORMAL, "\n=== CALCUL DE K-EFFECTIF (DIRECT) ===");
+        if (use_diagonal_solver && !(rt_ == 0 && p_ == 0)) { Log(VerbosityLevel::NORMAL, "  Note: Solveur diagonal non disponible (ordre > 0)"); use_diagonal_solver = false; }
+        if (use_diagonal_solver) Log(VerbosityLevel::NORMAL, "  Mode: Solveur diagonal RT0-P0 (faible RAM)");
+        Log(VerbosityLevel::NORMAL, "  Acceleration: Chebyshev");
+        chk(nf_set_phi(h_, Phi_.data()));
+        chk(nf_set_warm_state(h_, has_valid_keff_ ? 1 : 0, last_keff_));
+        nf_keff_opts o = make_opts(use_coarse_init, coarse_factors, use_diagonal_solver);
+        double k = 1.0; int nout = 0;
+        chk(nf_solve_keff(h_, &o, &k, &nout));
+        chk(nf_get_phi(h_, Phi_.data()));
+        if (verb_ >= VerbosityLevel::NORMAL) {
+            std::vector<double> hk(nout), hdk(nout), hdp(nout);
+            nf_get_history(h_, hk.data(), hdk.data(), hdp.data(), nullptr, nout);
+            for (int it = 0; it < nout; it += 5)
+                std::cout << "  It " << std::setw(4) << it << " : k = " << std::fixed << std::setprecision(8) << hk[it] << "  dk = " << std::scientific
+                          << std::setprecision(2) << hdk[it] << "  dphi = " << hdp[it] << std::defaultfloat << std::endl;
+            if (nout < max_outer_) std::cout << "  Convergence en " << nout << " iterations" << std::endl;
+            std::cout << "  k-eff direct = " << std::fixed << std::setprecision(8) << k << std::defaultfloat << std::endl;
+        }
+        has_valid_keff_ = true; last_keff_ = k;
+        return k;
+    }
+    std::pair<double, py::array_t<double>> SolveCoarse(const std::vector<int> &refine)
+    {
+        need_built("SolveCoarse");
+        chk(nf_set_phi(h_, Phi_.data()));
+        nf_keff_opts o = make_opts(true, refine, false);
+        py::array_t<double> out((py::ssize_t)(ng_ * nphi_));
+        double k = 1.0;
+        chk(nf_solve_coarse(h_, &o, &k, out.mutable_data()));
+        return {k, out};
+    }
+    void BuildDiagonalCache() { need_built("build_diagonal_cache"); chk(nf_build_diagonal_cache(h_)); }
+    py::array_t<double> GetCurrent()
+    {
+        need_built("get_current");
+        py::array_t<double> out((py::ssize_t)(ng_ * nJ_));
+        chk(nf_get_J(h_, out.mutable_data()));
+        return out;
+    }
+    std::map<int, int> GetBCMap() const { std::map<int, int> r; for (auto &kv : bc_types_) r[kv.first] = (int)kv.second; return r; }
+    [[noreturn]] void oos(const char *what, const char *ref) const
+    {
+        throw std::runtime_error(std::string(what) + " is outside the accelerated hot path of neutfem_amd (reference: " + ref + ")");
+    }
+
+    // ---- numpy views (src/NeutFEM.cpp:2626-2730) ---------------------------------------------------
+    py::array_t<double> view(std::vector<double> &v, bool sigs = false)
+    {
+        std::vector<py::ssize_t> shape; shape.push_back(ng_); if (sigs) shape.push_back(ng_);
+        if (dim_ >= 3) shape.push_back(nz_);
+        if (dim_ >= 2) shape.push_back(ny_);
+        shape.push_back(nx_);
+        std::vector<py::ssize_t> strides(shape.size()); py::ssize_t s = sizeof(double);
+        for (int i = (int)shape.size() - 1; i >= 0; --i) { strides[i] = s; s *= shape[i]; }
+        return py::array_t<double>(shape, strides, v.data(), py::cast(this));
+    }
+    py::array_t<double> flux(std::vector<double> &src, std::vector<double> &p0)
+    {
+        if (nloc_ == 1) return view(src);
+        p0.resize(ng_ * ne_);
+        for (int g = 0; g < ng_; ++g) for (long e = 0; e < ne_; ++e) p0[g * ne_ + e] = src[g * nphi_ + e * nloc_];
+        return view(p0);
+    }
+
+    int dim_, nx_, ny_, nz_, ng_, rt_, p_, nloc_;
+    long ne_, nphi_, nJ_, nJface_;
+    std::vector<double> xb_, yb_, zb_, D_, SRC_, SigR_, NSF_, KSF_, Chi_, SigS_, Phi_, PhiAdj_, fluxP0_, fluxAdjP0_;
+    double last_keff_ = 1.0, last_keff_adj_ = 1.0;
+
+private:
+    void Log(VerbosityLevel lvl, const std::string &s) const { if (verb_ >= lvl) std::cout << s << std::endl; }
+    void chk(int rc) const { if (rc != NF_OK) throw std::runtime_error(std::string("neutfem_amd: ") + nf_last_error()); }
+    void ensure_handle()
+    {
+        if (h_) return;
+        int dev = 0; if (const char *e = std::getenv("NEUTFEM_DEVICE")) dev = std::atoi(e);
+        else if (const char *lr = std::getenv("LOCAL_RANK")) dev = std::atoi(lr) % std::max(1, nf_device_count());
+        chk(nf_create(rt_, p_, ng_, (int)xb_.size(), xb_.data(), (int)yb_.size(), yb_.data(), (int)zb_.size(), zb_.data(), dev, &h_));
+    }
+    void need_built(const char *who) const { if (!h_) throw std::runtime_error(std::string(who) + ": call BuildMatrices() first"); }
+
+    nf_handle h_ = nullptr;
+    std::map<int, BCType> bc_types_; std::map<int, double> bc_values_; std::map<int, std::pair<double, double>> robin_;
+    LinearSolverType solver_ = LinearSolverType::BICGSTAB; bool solver_pushed_ = false;   // src/NeutFEM.cpp:126 vs solvers.cpp:68
+    double tol_keff_ = 1e-5, tol_flux_ = 1e-5, tol_L2_ = 1e-5; int max_outer_ = 200, max_inner_ = 1000;
+    VerbosityLevel verb_ = VerbosityLevel::NORMAL; double cmfd_omega_ = 0.7;
+    bool has_valid_keff_ = false;
+};
+
+PYBIND11_MODULE(_neutfem_eigen, m)
+{
+    m.doc() = "neutfem_amd: MI355X-native drop-in for jujuC31/NeutFEM's neutfem._neutfem_eigen (src/wrapper.cpp)";
+    m.attr("__backend__") = "hip-gfx950";
+    m.def("device_count", &nf_device_count, "number of visible HIP devices");
+
+    py::enum_<VerbosityLevel>(m, "VerbosityLevel")
+        .value("SILENT", VerbosityLevel::SILENT).value("NORMAL", VerbosityLevel::NORMAL)
+        .value("VERBOSE", VerbosityLevel::VERBOSE).value("DEBUG", VerbosityLevel::DEBUG);
+    py::enum_<BCType>(m, "BCType")
+        .value("DIRICHLET", BCType::DIRICHLET).value("NEUMANN", BCType::NEUMANN).value("ROBIN", BCType::ROBIN)
+        .value("MIRROR", BCType::MIRROR).value("PERIODIC", BCType::PERIODIC);
+    py::enum_<BoundaryID>(m, "BoundaryID")
+        .value("LEFT_1D", BoundaryID::LEFT_1D).value("RIGHT_1D", BoundaryID::RIGHT_1D)
+        .value("LEFT_2D", BoundaryID::LEFT_2D).value("RIGHT_2D", BoundaryID::RIGHT_2D)
+        .value("TOP_2D", BoundaryID::TOP_2D).value("BOTTOM_2D", BoundaryID::BOTTOM_2D)
+        .value("FRONT_3D", BoundaryID::FRONT_3D).value("BACK_3D", BoundaryID::BACK_3D)
+        .value("LEFT_3D", BoundaryID::LEFT_3D).value("RIGHT_3D", BoundaryID::RIGHT_3D)
+        .value("TOP_3D", BoundaryID::TOP_3D).value("BOTTOM_3D", BoundaryID::BOTTOM_3D);
+    py::enum_<LinearSolverType>(m, "LinearSolverType")
+        .value("DIRECT_LU", LinearSolverType::DIRECT_LU).value("DIRECT_LLT", LinearSolverType::DIRECT_LLT)
+        .value("DIRECT_LDLT", LinearSolverType::DIRECT_LDLT).value("CG", LinearSolverType::CG)
+        .value("CG_DIAG", LinearSolverType::CG_DIAG).value("CG_ICHOL", LinearSolverType::CG_ICHOL)
+        .value("BICGSTAB", LinearSolverType::BICGSTAB).value("BICGSTAB_DIAG", LinearSolverType::BICGSTAB_DIAG)
+        .value("BICGSTAB_ILU", LinearSolverType::BICGSTAB_ILU).value("LCG", LinearSolverType::LCG);
+
+    py::class_<NeutFEM>(m, "NeutFEM")
+        .def(py::init<int, int, arr_t, arr_t, arr_t>(), py::arg("order"), py::arg("ng"), py::arg("x_breaks"), py::arg("y_breaks"), py::arg("z_breaks"))
+        .def(py::init<int, int, int, arr_t, arr_t, arr_t>(), py::arg("rt_order"), py::arg("p_order"), py::arg("ng"), py::arg("x_breaks"),
+             py::arg("y_breaks"), py::arg("z_breaks"))
+        .def("set_bc", &NeutFEM::SetBC, py::arg("attr"), py::arg("type"), py::arg("value") = 0.0)
+        .def("set_robin_coefficients", &NeutFEM::SetRobin, py::arg("attr"), py::arg("alpha"), py::arg("beta"))
+        .def("set_linear_solver", &NeutFEM::SetLinearSolver, py::arg("solver_type"))
+        .def("set_tol", &NeutFEM::SetTolerance, py::arg("tol_keff"), py::arg("tol_flux"), py::arg("tol_L2"), py::arg("max_outer"), py::arg("max_inner"))
+        .def("set_verbosity", &NeutFEM::SetVerbosity, py::arg("level"))
+        .def("set_cmfd_relaxation", &NeutFEM::SetCMFDRelaxation, py::arg("omega"))
+        .def("apply_quarter_symmetry", &NeutFEM::ApplyQuarterSymmetry, py::arg("axis1") = 0, py::arg("axis2") = 1)
+        .def("add_refl", &NeutFEM::AddReflector, py::arg("D"), py::arg("SigR"), py::arg("SigS"))
+        .def("set_refl", &NeutFEM::SetReflector, py::arg("refl_id"), py::arg("dimension"), py::arg("is_upper"))
+        .def("clean_refl", &NeutFEM::ClearReflectors)
+        .def("BuildMatrices", &NeutFEM::BuildMatrices)
+        .def("SolveKeff", &NeutFEM::SolveKeff, py::arg("use_coarse_init") = false, py::arg("coarse_factors") = std::vector<int>{},
+             py::arg("use_diagonal_solver") = false, py::arg("use_cmfd") = false)
+        .def("SolveAdjoint", [](NeutFEM &s, bool, bool) -> double { s.oos("SolveAdjoint", "src/NeutFEM.cpp:1877-2082"); },
+             py::arg("normalize_to_direct") = true, py::arg("use_direct_keff") = true)
+        .def("SolveSubcritical", [](NeutFEM &s) { s.oos("SolveSubcritical", "declared at include/NeutFEM.hpp:279, never defined"); })
+        .def("SolveCoarse", &NeutFEM::SolveCoarse, py::arg("refine"))
+        .def("build_diagonal_cache", &NeutFEM::BuildDiagonalCache)
+        .def("initialize_cmfd", [](NeutFEM &s) { s.oos("initialize_cmfd", "src/NeutFEM.cpp:662-760"); })
+        .def("ExportVTK", [](NeutFEM &s, const std::string &, bool, bool, bool, bool) { s.oos("ExportVTK", "src/NeutFEM.cpp:2137-2332"); },
+             py::arg("filename"), py::arg("export_flux") = true, py::arg("export_current") = true, py::arg("export_xs") = false, py::arg("export_adjoint") = false)
+        .def("ExportFluxVTK", [](NeutFEM &s, const std::string &, bool) { s.oos("ExportFluxVTK", "src/NeutFEM.cpp:2324-2327"); }, py::arg("filename"), py::arg("adjoint") = false)
+        .def("ExportXSVTK", [](NeutFEM &s, const std::string &) { s.oos("ExportXSVTK", "src/NeutFEM.cpp:2329-2332"); }, py::arg("filename"))
+        .def("get_D", [](NeutFEM &s) { return s.view(s.D_); })
+        .def("get_SRC", [](NeutFEM &s) { return s.view(s.SRC_); })
+        .def("get_SigR", [](NeutFEM &s) { return s.view(s.SigR_); })
+        .def("get_NSF", [](NeutFEM &s) { return s.view(s.NSF_); })
+        .def("get_KSF", [](NeutFEM &s) { return s.view(s.KSF_); })
+        .def("get_Chi", [](NeutFEM &s) { return s.view(s.Chi_); })
+        .def("get_SigS", [](NeutFEM &s) { return s.view(s.SigS_, true); })
+        .def("get_flux", [](NeutFEM &s) { return s.flux(s.Phi_, s.fluxP0_); })
+        .def("get_flux_adj", [](NeutFEM &s) { return s.flux(s.PhiAdj_, s.fluxAdjP0_); })
+        .def("get_current", &NeutFEM::GetCurrent, "extension: Sol_J_ as a flat (ng*n_J) array in the reference DOF order")
+        .def("get_bc_map", &NeutFEM::GetBCMap, "extension: {attr: BCType value} as set through set_bc")
+        .def("reset_flux", &NeutFEM::ResetFlux)
+        .def("GetNumElements", [](const NeutFEM &s) { return s.ne_; })
+        .def("GetNumGroups", [](const NeutFEM &s) { return s.nphi_ / s.ne_; })      // reference bug kept, src/wrapper.cpp:953-955
+        .def("GetDimension", [](const NeutFEM &s) { return s.dim_; })
+        .def("GetLastKeff", [](const NeutFEM &s) { return s.last_keff_; })
+        .def("GetLastKeffAdjoint", [](const NeutFEM &s) { return s.last_keff_adj_; })
+        .def("GetSolverName", &NeutFEM::GetSolverName)
+        .def("project_flux", [](NeutFEM &s, const std::vector<int> &, bool) { s.oos("project_flux", "bound at src/wrapper.cpp:1003, never defined"); }, py::arg("refine"), py::arg("adjoint") = false)
+        .def("project_power", [](NeutFEM &s, const std::vector<int> &, bool) { s.oos("project_power", "bound at src/wrapper.cpp:1024, never defined"); }, py::arg("refine"), py::arg("adjoint") = false)
+        .def("zoom_resolved", [](NeutFEM &s, const std::vector<int> &, bool) { s.oos("zoom_resolved", "bound at src/wrapper.cpp:1045, never defined"); }, py::arg("refine"), py::arg("adjoint") = false);
+}

@@ -1,0 +1,602 @@
+// nf_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the NeutFEM hot path.
+//
+// Everything here is fp64 and HBM-bound: stencil differences, batched tridiagonal line
+// solves and streaming vector updates.  Design rules:
+//   * A^-1 along a grid line is a first-order linear recurrence in each sweep direction, so it
+//     is evaluated as a parallel scan of affine maps z -> a z + b instead of a serial Thomas
+//     sweep: lanes of one wavefront scan an x-line with cross-lane shuffles (k_schur_x), and
+//     y/z-lines are cut into register-resident segments whose summaries are combined through
+//     LDS (k_schur_s).  No intermediate of the line solve ever goes to HBM.
+//   * consecutive lanes always touch consecutive cells of the unit-stride x axis (coalesced
+//     512 B - 1 KiB per wave instruction).
+//   * reductions are two-stage with a fixed summation order (bitwise reproducible runs); the
+//     scalars of CG (alpha, beta, stop test) never leave the device inside a solve.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nf {
+
+// device-resident state of one CG solve (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636)
+struct CgScalars {
+    double rr, pAp, alpha, beta, rr_new, tol_sq, rhs_norm, tol;
+    int done, its, maxit, pad;
+};
+
+enum FinOp { FIN_RHS = 0, FIN_PAP = 1, FIN_RR = 2, FIN_SUM = 3 };
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// fixed-order block sum; result valid in thread 0.  sred: >= blockDim/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *sred)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sred[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) s += sred[i];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// second reduction stage + CG scalar logic.  One block of 256 threads.
+// partials: nq rows of `stride` doubles, `count` valid entries each.
+__global__ __launch_bounds__(256) void k_finalize(int op, const double *__restrict__ partials, int count, long stride,
+                                                  int nq, CgScalars *__restrict__ cg, double *__restrict__ out,
+                                                  double tol, int maxit)
+{
+    __shared__ double sred[4];
+    if (op == FIN_PAP || op == FIN_RR) { if (cg->done) return; }
+    double tot[4] = { 0, 0, 0, 0 };
+    for (int q = 0; q < nq; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < count; i += 256) s += partials[q * stride + i];
+        s = block_sum(s, sred);
+        tot[q] = s;
+    }
+    if (threadIdx.x != 0) return;
+    if (op == FIN_RHS) {                       // src/solvers.cpp:587-592
+        cg->rr = tot[0];
+        cg->rhs_norm = sqrt(tot[0]);
+        cg->tol = tol;
+        cg->tol_sq = tol * tol * cg->rhs_norm * cg->rhs_norm;
+        cg->done = 0; cg->its = 0; cg->maxit = maxit;
+        if (maxit <= 0) cg->done = 1;
+    } else if (op == FIN_PAP) {                // src/solvers.cpp:602-606
+        cg->pAp = tot[0];
+        if (fabs(tot[0]) < 1e-30) cg->done = 1;
+        else cg->alpha = cg->rr / tot[0];
+    } else if (op == FIN_RR) {                 // src/solvers.cpp:613-631
+        cg->rr_new = tot[0];
+        cg->its += 1;
+        if (tot[0] < cg->tol_sq) { cg->rr = tot[0]; cg->done = 1; }
+        else {
+            cg->beta = tot[0] / cg->rr;
+            cg->rr = tot[0];
+            if (cg->its >= cg->maxit) cg->done = 1;
+        }
+    } else {
+        for (int q = 0; q < nq; ++q) out[q] = tot[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BuildMatrices, per-cell part (src/NeutFEM.cpp:1163-1302): C diag, fission and scatter diagonals.
+// P0: C_ee = SigR*detJ*C-hat = SigR*V ; M_fiss = nsf*V ; entries <= 1e-14 dropped.
+__global__ void k_cell_coef(const double *__restrict__ xs, double *__restrict__ out, const double *__restrict__ hx,
+                            const double *__restrict__ hy, const double *__restrict__ hz, int nx, int ny, long N,
+                            int mode /*0: threshold on product (C), 1: threshold on xs (fission/scatter)*/)
+{
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int ix = (int)(e % nx); const long r = e / nx; const int iy = (int)(r % ny); const int iz = (int)(r / ny);
+        const double V = hx[ix] * hy[iy] * hz[iz];
+        const double s = xs[e];
+        double v = s * V;
+        if (mode == 0) { if (!(fabs(v) > 1e-14)) v = 0.0; }
+        else { if (!(fabs(s) > 1e-14)) v = 0.0; }
+        out[e] = v;
+    }
+}
+
+struct Geom {
+    int dim, nx, ny, nz;
+    const double *hx, *hy, *hz;
+    double cLL, cLR, beta;       // RT0 unit tables: A-hat = 2^(dim-1) [[2/3,1/3],[1/3,2/3]], B-hat = -+2^(dim-1)
+    int dir_lo[3], dir_hi[3];    // Dirichlet flags per direction (src/NeutFEM.cpp:2338-2347 attribute map)
+};
+
+// geometric factor of direction d for cell (ix,iy,iz), src/FEM.cpp:795-813 (2D quirk kept)
+__device__ __forceinline__ double geom_factor(const Geom &G, int d, int ix, int iy, int iz)
+{
+    const double hx = G.hx[ix], hy = G.hy[iy], hz = G.hz[iz];
+    if (G.dim == 1) return hx / 2.0;
+    if (G.dim == 2) return d == 0 ? hy / hx : hx / hy;
+    if (d == 0) return 2.0 * hx / (hy * hz);
+    if (d == 1) return 2.0 * hy / (hx * hz);
+    return 2.0 * hz / (hx * hy);
+}
+// Dirichlet diagonal term I_f * 2 * D (src/NeutFEM.cpp:1350, 1458-1489)
+__device__ __forceinline__ double dirichlet_term(const Geom &G, int d, int ix, int iy, int iz, double D)
+{
+    double area = d == 0 ? G.hy[iy] * G.hz[iz] : d == 1 ? G.hx[ix] * G.hz[iz] : G.hx[ix] * G.hy[iy];
+    double I = G.dim == 1 ? 1.0 : G.dim == 2 ? 2.0 * 2.0 / area : 4.0 * 2.0 * 2.0 / area;
+    return I * 2.0 * D;
+}
+__device__ __forceinline__ void cell_a(const Geom &G, int d, int ix, int iy, int iz, double D, double &a2, double &a1)
+{
+    const double a = (1.0 / D) * geom_factor(G, d, ix, iy, iz);
+    a2 = G.cLL * a; if (!(fabs(a2) > 1e-14)) a2 = 0.0;      // src/NeutFEM.cpp:1064 drop threshold
+    a1 = G.cLR * a; if (!(fabs(a1) > 1e-14)) a1 = 0.0;
+}
+
+// AssembleA + ApplyDirichletToA + SparseLU (src/NeutFEM.cpp:1036-1076,1328-1456; src/solvers.cpp:163)
+// for one direction: one thread per grid line assembles the tridiagonal T of that line on the fly
+// and stores its LDL^T factor cell-aligned: L[e] couples the lower to the upper face of cell e,
+// DR[e] = 1/d'(upper face of e), D0[line] = 1/d'(first face).
+__global__ void k_factor_lines(Geom G, int d, const double *__restrict__ D, double *__restrict__ L,
+                               double *__restrict__ DR, double *__restrict__ D0, long nlines)
+{
+    const long line = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (line >= nlines) return;
+    int n, ix = 0, iy = 0, iz = 0; long base, sl;
+    const long nxy = (long)G.nx * G.ny;
+    if (d == 0) { n = G.nx; iy = (int)(line % G.ny); iz = (int)(line / G.ny); base = line * G.nx; sl = 1; }
+    else if (d == 1) { n = G.ny; ix = (int)(line % G.nx); iz = (int)(line / G.nx); base = iz * nxy + ix; sl = G.nx; }
+    else { n = G.nz; ix = (int)(line % G.nx); iy = (int)(line / G.nx); base = line; sl = nxy; }
+    int *ci = d == 0 ? &ix : d == 1 ? &iy : &iz;
+    *ci = 0;
+    double Dc = D[base], a2, a1;
+    cell_a(G, d, ix, iy, iz, Dc, a2, a1);
+    double dprev = a2 + (G.dir_lo[d] ? dirichlet_term(G, d, ix, iy, iz, Dc) : 0.0);
+    D0[line] = 1.0 / dprev;
+    for (int c = 0; c < n; ++c) {
+        double diag_next;
+        double na2 = 0.0, na1 = 0.0;
+        if (c + 1 < n) {
+            *ci = c + 1;
+            const double Dn = D[base + (long)(c + 1) * sl];
+            cell_a(G, d, ix, iy, iz, Dn, na2, na1);
+            diag_next = a2 + na2;
+        } else {
+            *ci = c;
+            diag_next = a2 + (G.dir_hi[d] ? dirichlet_term(G, d, ix, iy, iz, Dc) : 0.0);
+        }
+        const double l = a1 / dprev;
+        const double dn = diag_next - l * a1;
+        L[base + (long)c * sl] = l;
+        DR[base + (long)c * sl] = 1.0 / dn;
+        dprev = dn;
+        if (c + 1 < n) { Dc = D[base + (long)(c + 1) * sl]; a2 = na2; a1 = na1; }
+    }
+}
+
+// BuildDiagonalSchurCache (src/NeutFEM.cpp:483-597): S_inv(e) = 1/(C_ee + sum_faces B_ef^2 / A_ff)
+__global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double *__restrict__ Cd,
+                             double *__restrict__ Sinv, long N)
+{
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int ix = (int)(e % G.nx); const long r = e / G.nx; const int iy = (int)(r % G.ny); const int iz = (int)(r / G.ny);
+    const long nxy = (long)G.nx * G.ny;
+    double S = Cd[e];
+    const double b2 = G.beta * G.beta;
+    for (int d = 0; d < G.dim; ++d) {
+        const int c = d == 0 ? ix : d == 1 ? iy : iz;
+        const int n = d == 0 ? G.nx : d == 1 ? G.ny : G.nz;
+        const long sl = d == 0 ? 1 : d == 1 ? G.nx : nxy;
+        double a2, a1, b2n, b1n;
+        cell_a(G, d, ix, iy, iz, D[e], a2, a1);
+        // lower face
+        double Alo = a2, Ahi = a2;
+        if (c > 0) {
+            int jx = ix - (d == 0), jy = iy - (d == 1), jz = iz - (d == 2);
+            cell_a(G, d, jx, jy, jz, D[e - sl], b2n, b1n); Alo += b2n;
+        } else if (G.dir_lo[d]) Alo += dirichlet_term(G, d, ix, iy, iz, D[e]);
+        if (c + 1 < n) {
+            int jx = ix + (d == 0), jy = iy + (d == 1), jz = iz + (d == 2);
+            cell_a(G, d, jx, jy, jz, D[e + sl], b2n, b1n); Ahi += b2n;
+        } else if (G.dir_hi[d]) Ahi += dirichlet_term(G, d, ix, iy, iz, D[e]);
+        if (fabs(Alo) > 1e-14) S += b2 / Alo;
+        if (fabs(Ahi) > 1e-14) S += b2 / Ahi;
+    }
+    Sinv[e] = fabs(S) > 1e-14 ? 1.0 / S : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schur apply, x direction (unit stride along the line).  One wavefront scans 64/LPL lines;
+// a lane owns K consecutive cells per chunk of LPL*K cells, NCH chunks cover the line.
+//   y[c] = (first ? Cd[c]*x[c] : y[c]) + beta*(u[c+1]-u[c]),   T u = t,  t_f = beta*(x[f-1]-x[f])
+// Forward  z_{c+1} = t_{c+1} - L[c] z_c, w = z * dinv ; backward u_f = w_f - L[f] u_{f+1}.
+template <int K, int NCH, bool VEC>
+__global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, double *__restrict__ y,
+                                                 const double *__restrict__ L, const double *__restrict__ DR,
+                                                 const double *__restrict__ D0, const double *__restrict__ Cd,
+                                                 int nx, long nlines, int lpl_log2, double beta, int first, int last,
+                                                 double *__restrict__ partials, const CgScalars *__restrict__ cg)
+{
+    __shared__ double sred[4];
+    if (cg && cg->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int LPL = 1 << lpl_log2, LPW = 64 >> lpl_log2;
+    const int li = lane & (LPL - 1), sub = lane >> lpl_log2;
+    const long line = ((long)blockIdx.x * 4 + wave) * LPW + sub;
+    const bool lv = line < nlines;
+    const long base = lv ? line * nx : 0;
+    double xs[NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], yo[NCH][K];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = (ch * LPL + li) * K;
+        if (VEC) {
+            static_assert(!VEC || K == 2, "vector path is K=2");
+            const bool ok = lv && c0 < nx;
+            double2 vx = make_double2(0, 0), vl = vx, vr = vx, vy = vx;
+            if (ok) {
+                vx = *reinterpret_cast<const double2 *>(x + base + c0);
+                vl = *reinterpret_cast<const double2 *>(L + base + c0);
+                vr = *reinterpret_cast<const double2 *>(DR + base + c0);
+                vy = first ? *reinterpret_cast<const double2 *>(Cd + base + c0) : *reinterpret_cast<const double2 *>(y + base + c0);
+            }
+            xs[ch][0] = vx.x; xs[ch][K - 1] = vx.y; Ls[ch][0] = vl.x; Ls[ch][K - 1] = vl.y;
+            Rs[ch][0] = vr.x; Rs[ch][K - 1] = vr.y; yo[ch][0] = vy.x; yo[ch][K - 1] = vy.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int c = c0 + j; const bool ok = lv && c < nx;
+                xs[ch][j] = ok ? x[base + c] : 0.0;
+                Ls[ch][j] = ok ? L[base + c] : 0.0;
+                Rs[ch][j] = ok ? DR[base + c] : 0.0;
+                yo[ch][j] = ok ? (first ? Cd[base + c] : y[base + c]) : 0.0;
+            }
+        }
+    }
+    const double d0 = lv ? D0[line] : 0.0;
+    const double z0 = __shfl(-beta * xs[0][0], 0, LPL);
+    // ---- forward sweep over chunks
+    double carry = z0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        double xn = __shfl_down(xs[ch][0], 1, LPL);
+        double xc = 0.0;
+        if (ch + 1 < NCH) xc = __shfl(xs[ch + 1 < NCH ? ch + 1 : ch][0], 0, LPL);
+        if (li == LPL - 1) xn = xc;
+        double t[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) t[j] = beta * (xs[ch][j] - (j + 1 < K ? xs[ch][j + 1 < K ? j + 1 : j] : xn));
+        double A = 1.0, B = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { B = t[j] - Ls[ch][j] * B; A = -Ls[ch][j] * A; }
+        for (int d = 1; d < LPL; d <<= 1) {
+            const double Ap = __shfl_up(A, d, LPL), Bp = __shfl_up(B, d, LPL);
+            if (li >= d) { B = A * Bp + B; A = A * Ap; }
+        }
+        const double Ae = __shfl_up(A, 1, LPL), Be = __shfl_up(B, 1, LPL);
+        double z = li == 0 ? carry : Ae * carry + Be;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { z = t[j] - Ls[ch][j] * z; w[ch][j] = z * Rs[ch][j]; }
+        carry = __shfl(z, LPL - 1, LPL);
+    }
+    // ---- backward sweep over chunks
+    double ucarry = 0.0, dot = 0.0;
+#pragma unroll
+    for (int ch = NCH - 1; ch >= 0; --ch) {
+        double Ln = __shfl_down(Ls[ch][0], 1, LPL);
+        double Lc = 0.0;
+        if (ch + 1 < NCH) Lc = __shfl(Ls[ch + 1 < NCH ? ch + 1 : ch][0], 0, LPL);
+        if (li == LPL - 1) Ln = Lc;
+        double Lup[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) Lup[j] = j + 1 < K ? Ls[ch][j + 1 < K ? j + 1 : j] : Ln;
+        double A = 1.0, B = 0.0;
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) { B = w[ch][j] - Lup[j] * B; A = -Lup[j] * A; }
+        for (int d = 1; d < LPL; d <<= 1) {
+            const double Ap = __shfl_down(A, d, LPL), Bp = __shfl_down(B, d, LPL);
+            if (li + d < LPL) { B = A * Bp + B; A = A * Ap; }
+        }
+        const double Ae = __shfl_down(A, 1, LPL), Be = __shfl_down(B, 1, LPL);
+        double u = li == LPL - 1 ? ucarry : Ae * ucarry + Be;
+        double uv[K];
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) { u = w[ch][j] - Lup[j] * u; uv[j] = u; }
+        ucarry = __shfl(uv[0], 0, LPL);
+        double ulo = __shfl_up(uv[K - 1], 1, LPL);
+        double wprev = 0.0;
+        if (ch > 0) wprev = __shfl(w[ch > 0 ? ch - 1 : 0][K - 1], LPL - 1, LPL);
+        if (li == 0) ulo = (ch == 0 ? z0 * d0 : wprev) - Ls[ch][0] * uv[0];
+        double yv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double lo = j == 0 ? ulo : uv[j > 0 ? j - 1 : 0];
+            const double add = beta * (uv[j] - lo);
+            yv[j] = (first ? yo[ch][j] * xs[ch][j] : yo[ch][j]) + add;
+            dot += xs[ch][j] * yv[j];           // padded cells have x = 0
+        }
+        const int c0 = (ch * LPL + li) * K;
+        if (VEC) {
+            if (lv && c0 < nx) *reinterpret_cast<double2 *>(y + base + c0) = make_double2(yv[0], yv[K - 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) if (lv && c0 + j < nx) y[base + c0 + j] = yv[j];
+        }
+    }
+    if (last && partials) {
+        const double s = block_sum(dot, sred);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schur apply, y or z direction.  Thread = (ix lane, segment of SEG cells along the line) with
+// the segment held in registers; segment summaries (affine maps) are exchanged through LDS.
+// Always accumulates into y (the x pass ran first).  Grid: (ceil(nx/TX), n_outer).
+template <int SEG>
+__global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ L,
+                          const double *__restrict__ DR, const double *__restrict__ D0, int n, long sl,
+                          long outer_stride, int nx, int TX, int NSEG, double beta, int last,
+                          double *__restrict__ partials, const CgScalars *__restrict__ cg)
+{
+    extern __shared__ double sm[];
+    if (cg && cg->done) return;
+    const int T = TX * NSEG;
+    double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T, *sred = sm + 4 * T + TX;
+    const int tid = threadIdx.x, ixl = tid % TX, seg = tid / TX;
+    const int ix = blockIdx.x * TX + ixl;
+    const bool valid = ix < nx;
+    const long base = (long)blockIdx.y * outer_stride + ix;
+    const int c0 = seg * SEG;
+    double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];
+#pragma unroll
+    for (int i = 0; i <= SEG; ++i) {
+        const int c = c0 + i; const bool ok = valid && c < n;
+        const long a = base + (long)c * sl;
+        xv[i] = ok ? x[a] : 0.0;
+        Lv[i] = ok ? L[a] : 0.0;
+        if (i < SEG) { Rv[i] = ok ? DR[a] : 0.0; yo[i] = ok ? y[a] : 0.0; }
+    }
+    double dinv_s = 0.0;
+    if (valid && c0 < n) dinv_s = c0 == 0 ? D0[(long)blockIdx.y * nx + ix] : DR[base + (long)(c0 - 1) * sl];
+    double t[SEG];
+    double P = 1.0, lz = 0.0;
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { t[i] = beta * (xv[i] - xv[i + 1]); lz = t[i] - Lv[i] * lz; P = -Lv[i] * P; }
+    sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz;
+    if (seg == 0) sZ0[ixl] = -beta * xv[0];
+    __syncthreads();
+    double z = sZ0[ixl];
+    for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
+    const double zin = z;
+    double w[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { z = t[i] - Lv[i] * z; w[i] = z * Rv[i]; }
+    double Q = 1.0, lu = 0.0;
+#pragma unroll
+    for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
+    sA2[seg * TX + ixl] = Q; sB2[seg * TX + ixl] = lu;
+    __syncthreads();
+    double u = 0.0;
+    for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];
+#pragma unroll
+    for (int i = SEG - 1; i >= 0; --i) { u = w[i] - Lv[i + 1] * u; w[i] = u; }
+    const double ulo = zin * dinv_s - Lv[0] * w[0];
+    double dot = 0.0;
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+        const double yv = yo[i] + beta * (w[i] - (i == 0 ? ulo : w[i > 0 ? i - 1 : 0]));
+        const int c = c0 + i;
+        if (valid && c < n) { y[base + (long)c * sl] = yv; dot += xv[i] * yv; }
+    }
+    if (last && partials) {
+        const double s = block_sum(dot, sred);
+        if (tid == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CG vector kernels (src/solvers.cpp:577-631).  Fixed grids, grid-stride loops.
+__global__ __launch_bounds__(256) void k_cg_init(const double *__restrict__ rhs, double *__restrict__ x,
+                                                 double *__restrict__ r, double *__restrict__ p, long n,
+                                                 double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const double b = rhs[i];
+        x[i] = 0.0; r[i] = b; p[i] = b; s += b * b;
+    }
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cg_update(double *__restrict__ x, double *__restrict__ r,
+                                                   const double *__restrict__ p, const double *__restrict__ q, long n,
+                                                   const CgScalars *__restrict__ cg, double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    if (cg->done) return;
+    const double alpha = cg->alpha;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        x[i] += alpha * p[i];
+        const double rn = r[i] - alpha * q[i];
+        r[i] = rn; s += rn * rn;
+    }
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cg_pupdate(double *__restrict__ p, const double *__restrict__ r, long n,
+                                                    const CgScalars *__restrict__ cg)
+{
+    if (cg->done) return;
+    const double beta = cg->beta;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) p[i] = r[i] + beta * p[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// power iteration kernels (src/NeutFEM.cpp:1694-1788)
+// total_fiss = sum_g M_fiss[g] phi_g ; partial sum of entries (prod_old)        (:1700-1707)
+__global__ __launch_bounds__(256) void k_fission(const double *__restrict__ Mf, const double *__restrict__ phi, int ng,
+                                                 long n, double *__restrict__ tf, double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        double v = 0.0;
+        for (int g = 0; g < ng; ++g) v += Mf[g * n + i] * phi[g * n + i];
+        tf[i] = v; s += v;
+    }
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+struct ScatterArgs { const double *M[64]; int ng; };
+// rhs = chi_g * total_fiss / k + sum_{gp != g} M_scatter[g<-gp] phi_gp  (Gauss-Seidel: gp < g from the new
+// iterate, gp > g from the old one) (:1716-1726).  If sinv != NULL the diagonal solve phi = S_inv * rhs is
+// fused (:607-613) and written to out, otherwise out = rhs.
+__global__ __launch_bounds__(256) void k_group_rhs(ScatterArgs sa, int g, const double *__restrict__ chi,
+                                                   const double *__restrict__ tf, double inv_k,
+                                                   const double *__restrict__ phi_new, const double *__restrict__ phi_old,
+                                                   const double *__restrict__ sinv, double *__restrict__ out, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        double v = inv_k * (chi[i] * tf[i]);
+        for (int gp = 0; gp < sa.ng; ++gp) {
+            if (gp == g || !sa.M[gp]) continue;
+            const double *ph = gp < g ? phi_new : phi_old;
+            v += sa.M[gp][i] * ph[gp * n + i];
+        }
+        out[i] = sinv ? sinv[i] * v : v;
+    }
+}
+// partial sums of prod_new, ||phi||^2, ||phi - phi_old||^2 over all groups       (:1766-1779)
+__global__ __launch_bounds__(256) void k_outer_reduce(const double *__restrict__ Mf, const double *__restrict__ phi,
+                                                      const double *__restrict__ old, long ntot,
+                                                      double *__restrict__ partials, long stride)
+{
+    __shared__ double sred[4];
+    double sp = 0.0, sn = 0.0, sd = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < ntot; i += gridDim.x * 256L) {
+        const double v = phi[i], d = v - old[i];
+        sp += Mf[i] * v; sn += v * v; sd += d * d;
+    }
+    sp = block_sum(sp, sred); sn = block_sum(sn, sred); sd = block_sum(sd, sred);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = sp; partials[stride + blockIdx.x] = sn; partials[2 * stride + blockIdx.x] = sd; }
+}
+// phi /= norm, then ChebyshevAccel::operator() (src/solvers.cpp:720-756).  mode 0: no acceleration,
+// 1: store phi0, 2: phi1 = phi0 + a1 (phi - phi0), 3: three-term.  cur <- result.
+__global__ __launch_bounds__(256) void k_normalize_cheb(const double *__restrict__ raw, double *__restrict__ cur,
+                                                        double *__restrict__ p0, double *__restrict__ p1, long ntot,
+                                                        double norm, int do_norm, int mode, double ca, double cb)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < ntot; i += gridDim.x * 256L) {
+        double v = raw[i];
+        if (do_norm) v /= norm;
+        if (mode == 1) p0[i] = v;
+        else if (mode == 2) { const double a = p0[i]; v = a + ca * (v - a); p1[i] = v; }
+        else if (mode == 3) {
+            const double a = p0[i], b = p1[i];
+            v = b + ca * (v - b) + cb * (b - a);
+            p0[i] = v;                       // caller swaps p0/p1: p0 <- old p1, p1 <- new
+        }
+        cur[i] = v;
+    }
+}
+
+// SolveCoarse: arithmetic volume-weighted block means (src/NeutFEM.cpp:2494-2556), one thread per coarse cell
+__global__ void k_coarsen(const double *__restrict__ fine, double *__restrict__ coarse, const double *__restrict__ xb,
+                          const double *__restrict__ yb, const double *__restrict__ zb, int dim, int nx, int ny, int nz,
+                          int rx, int ry, int rz, int nfields)
+{
+    const int nxc = nx / rx, nyc = ny / ry, nzc = nz / rz;
+    const long Nc = (long)nxc * nyc * nzc, Nf = (long)nx * ny * nz;
+    const long ec = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (ec >= Nc) return;
+    const int kx = (int)(ec % nxc), ky = (int)((ec / nxc) % nyc), kz = (int)(ec / ((long)nxc * nyc));
+    for (int f = 0; f < nfields; ++f) {
+        double vt = 0.0, s = 0.0;
+        for (int sz = 0; sz < rz; ++sz) for (int sy = 0; sy < ry; ++sy) for (int sx = 0; sx < rx; ++sx) {
+            const int ixf = kx * rx + sx, iyf = ky * ry + sy, izf = kz * rz + sz;
+            double vol = xb[ixf + 1] - xb[ixf];
+            if (dim >= 2) vol *= yb[iyf + 1] - yb[iyf];
+            if (dim >= 3) vol *= zb[izf + 1] - zb[izf];
+            vt += vol;
+            s += vol * fine[f * Nf + ((long)izf * ny + iyf) * nx + ixf];
+        }
+        coarse[f * Nc + ec] = s / vt;
+    }
+}
+// prolongation: piecewise-constant injection (src/NeutFEM.cpp:2585-2606)
+__global__ void k_prolong(const double *__restrict__ coarse, double *__restrict__ fine, int nx, int ny, int nz, int rx,
+                          int ry, int rz, int ng)
+{
+    const long Nf = (long)nx * ny * nz;
+    const int nxc = nx / rx, nyc = ny / ry; const long Nc = (long)nxc * nyc * (nz / rz);
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= Nf) return;
+    const int ix = (int)(e % nx), iy = (int)((e / nx) % ny), iz = (int)(e / ((long)nx * ny));
+    const long ec = ((long)(iz / rz) * nyc + iy / ry) * nxc + ix / rx;
+    for (int g = 0; g < ng; ++g) fine[g * Nf + e] = coarse[g * Nc + ec];
+}
+
+// J reconstruction (src/solvers.cpp:227-228 full path: J = -A^-1 B^T phi ; src/NeutFEM.cpp:620-633 diagonal
+// path: J_f = +(B^T phi)_f / A_ff).  One thread per line, Thomas in place in the face array (run once).
+__global__ void k_flux_to_J(Geom G, int d, const double *__restrict__ D, const double *__restrict__ phi,
+                            const double *__restrict__ L, const double *__restrict__ DR, const double *__restrict__ D0,
+                            double *__restrict__ J, long nlines, int diag)
+{
+    const long line = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (line >= nlines) return;
+    int n, ix = 0, iy = 0, iz = 0; long base, sl, fbase, fsl;
+    const long nxy = (long)G.nx * G.ny;
+    if (d == 0) { n = G.nx; iy = (int)(line % G.ny); iz = (int)(line / G.ny); base = line * G.nx; sl = 1; fbase = line * (G.nx + 1); fsl = 1; }
+    else if (d == 1) { n = G.ny; ix = (int)(line % G.nx); iz = (int)(line / G.nx); base = iz * nxy + ix; sl = G.nx;
+                       fbase = (long)iz * (G.ny + 1) * G.nx + ix; fsl = G.nx; }
+    else { n = G.nz; ix = (int)(line % G.nx); iy = (int)(line / G.nx); base = line; sl = nxy; fbase = line; fsl = nxy; }
+    const double beta = G.beta;
+    if (!diag) {
+        double z = -beta * phi[base];
+        J[fbase] = z * D0[line];
+        double xc = phi[base];
+        for (int c = 0; c < n; ++c) {
+            const double xn = c + 1 < n ? phi[base + (long)(c + 1) * sl] : 0.0;
+            z = beta * (xc - xn) - L[base + (long)c * sl] * z;
+            J[fbase + (long)(c + 1) * fsl] = z * DR[base + (long)c * sl];
+            xc = xn;
+        }
+        double u = J[fbase + (long)n * fsl];
+        J[fbase + (long)n * fsl] = -u;
+        for (int c = n - 1; c >= 0; --c) {
+            u = J[fbase + (long)c * fsl] - L[base + (long)c * sl] * u;
+            J[fbase + (long)c * fsl] = -u;
+        }
+    } else {
+        int *ci = d == 0 ? &ix : d == 1 ? &iy : &iz;
+        double a2p = 0.0, a1, xp = 0.0, Dp = 0.0;
+        for (int f = 0; f <= n; ++f) {
+            double a2 = 0.0, xc = 0.0, Dc = 0.0;
+            if (f < n) { *ci = f; Dc = D[base + (long)f * sl]; cell_a(G, d, ix, iy, iz, Dc, a2, a1); xc = phi[base + (long)f * sl]; }
+            double Aff = a2p + a2;
+            if (f == 0 && G.dir_lo[d]) { *ci = 0; Aff += dirichlet_term(G, d, ix, iy, iz, Dc); }
+            if (f == n && G.dir_hi[d]) { *ci = n - 1; Aff += dirichlet_term(G, d, ix, iy, iz, Dp); }
+            const double tt = beta * (xp - xc);
+            J[fbase + (long)f * fsl] = fabs(Aff) < 1e-14 ? 0.0 : tt / Aff;
+            a2p = a2; xp = xc; Dp = Dc;
+        }
+    }
+}
+
+// fill with a deterministic pseudo-random pattern (profiling helper)
+__global__ void k_fill_pattern(double *__restrict__ v, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        unsigned long long s = (unsigned long long)i * 6364136223846793005ULL + 1442695040888963407ULL;
+        s ^= s >> 29;
+        v[i] = (double)(s & 0xFFFFFF) / 16777216.0 - 0.5;
+    }
+}
+
+}  // namespace nf

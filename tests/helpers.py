@@ -1,0 +1,73 @@
+"""Shared set-up for the parity tests: build the oracle and the HIP solver from the same input dict."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TEST_TOL = (1e-5, 1e-4, 1e-4, 200, 1000)      # reference drivers: set_tol(1e-5,1e-4,1e-4,200,1000)
+
+
+def load_inputs(name):
+    z = np.load(os.path.join(GOLDEN, f"inputs_{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, f"golden_{name}.json")) as f:
+        return json.load(f)
+
+
+def make_oracle(inp, rt=0, p=0):
+    from oracle.oracle import OracleNeutFEM
+    o = OracleNeutFEM(rt, p, int(inp["ng"]), inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    o.set_linear_solver(6)
+    for a, t in zip(inp["bc_attr"], inp["bc_type"]):
+        o.set_bc(int(a), int(t), 0.0)
+    o.get_D()[...] = inp["D"]; o.get_SigR()[...] = inp["SigR"]; o.get_NSF()[...] = inp["NSF"]
+    o.get_Chi()[...] = inp["Chi"]; o.get_SigS()[...] = inp["SigS"]
+    o.BuildMatrices()
+    return o
+
+
+def make_hip(inp, rt=0, p=0, device=0):
+    from neutfem_amd.capi import HipSolver
+    s = HipSolver(rt, p, int(inp["ng"]), inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], device)
+    s.set_linear_solver(6)
+    for a, t in zip(inp["bc_attr"], inp["bc_type"]):
+        s.set_bc(int(a), int(t))
+    s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"])
+    s.build()
+    return s
+
+
+def synthetic_inputs(nx, ny, nz, ng, seed=0, dirichlet=(1, 2, 3, 4, 5, 6), nonuniform=True, void_frac=0.05):
+    """random heterogeneous problem with a few strong absorbers.  (Not Sigma = 1e15 like IAEA-3D's F6: scattered
+    cells of that kind give cond(S) ~ 1e20, on which the reference's unpreconditioned CG stagnates on any
+    hardware -- such a case tests nothing.)"""
+    rng = np.random.default_rng(seed)
+    def brk(n):
+        if n <= 1: return np.array([0.0])
+        h = rng.uniform(0.5, 2.5, n) if nonuniform else np.full(n, 1.25)
+        return np.concatenate([[0.0], np.cumsum(h)])
+    shape = tuple(n for n in (nz, ny, nx) if n > 1) or (nx,)
+    if len(shape) == 1: shape = (nx,)
+    D = rng.uniform(0.2, 2.0, (ng,) + shape); SigR = rng.uniform(0.01, 0.2, (ng,) + shape)
+    NSF = rng.uniform(0.0, 0.15, (ng,) + shape) * (rng.random((ng,) + shape) > 0.3)
+    Chi = np.zeros((ng,) + shape); Chi[0] = 1.0
+    if ng > 1: Chi[0] = 0.8; Chi[1] = 0.2
+    SigS = np.zeros((ng, ng) + shape)
+    for g in range(1, ng): SigS[g, g - 1] = rng.uniform(0.005, 0.05, shape)
+    if ng > 2: SigS[ng - 2, ng - 1] = rng.uniform(0.0, 0.003, shape)      # one up-scatter block
+    void = rng.random(shape) < void_frac
+    D[:, void] = 0.05; SigR[:, void] = 50.0; NSF[:, void] = 0.0; Chi[:, void] = 0.0; SigS[:, :, void] = 0.0
+    dim = 3 if nz > 1 else (2 if ny > 1 else 1)
+    valid = {1: (1, 2), 2: (1, 2, 3, 4), 3: (1, 2, 3, 4, 5, 6)}[dim]
+    attrs = [a for a in dirichlet if a in valid]
+    return dict(x_breaks=brk(nx), y_breaks=brk(ny), z_breaks=brk(nz), D=D, SigR=SigR, NSF=NSF, Chi=Chi, SigS=SigS,
+                bc_attr=np.array(attrs, int), bc_type=np.zeros(len(attrs), int), coarse_factors=np.array([1, 1, 1]), kref=1.0, ng=ng)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a).ravel(); b = np.asarray(b).ravel()
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
