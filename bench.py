@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- outer power-iterations per second of the multigroup k-eigenvalue solve (BASELINE.json metric).
+
+Workload (config.workload): IAEA-3D core resampled on a uniform n^3 mesh (default 256^3 = BASELINE configs[3] /
+SURVEY C4; fits one MI355X), 2 groups, RT0-P0, six Dirichlet sides, FULL Schur path exactly as the reference
+drivers run it (unpreconditioned CG to 1e-4 per group, Chebyshev-accelerated power iteration).
+A "step" is one outer power iteration (fission source, ng group solves, k update, normalise, Chebyshev).
+Inputs are uploaded and the line systems factored before the timed region; the timed region is K outer
+iterations bracketed by barrier + device synchronize; value = K / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel of the hot path (slowest Schur-apply direction pass): algorithmic bytes per
+                launch / mean launch duration measured with HIP events on the solver's stream inside the timed
+                region (DESIGN.md "Algorithmic bytes"); peak 8.0 TB/s.
+  cpu_baseline  the CPU oracle (oracle/nf_oracle.c, 1 core, kind "port") timed on a bounded sample of the same
+                workload: a fixed number of CG iterations on the same n^3 operator, extrapolated with the CG
+                counts of the timed GPU steps.  Rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=256, help="cells per axis of the resampled IAEA-3D mesh")
+    ap.add_argument("--case", default="iaea3d", choices=["iaea3d", "checker"])
+    ap.add_argument("--groups", type=int, default=8, help="groups of the synthetic checkerboard case")
+    ap.add_argument("--cpu-sample-iters", type=int, default=6, help="CG iterations timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-converge", action="store_true", help="skip the untimed converged solve (k-eff, pcm)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the small-mesh GPU-vs-oracle parity probe")
+    return ap.parse_args()
+
+
+def make_solver(case, device):
+    from neutfem_amd.capi import HipSolver
+    s = HipSolver(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], case["z_breaks"], device)
+    s.set_linear_solver(6)                                      # BICGSTAB, as every reference driver
+    for a, t in case["bc"]:
+        s.set_bc(a, t)
+    s.upload_xs(case["D"], case["SigR"], case["NSF"], case["Chi"], case["SigS"])
+    s.build()
+    return s
+
+
+def make_oracle(case):
+    from oracle.oracle import OracleNeutFEM
+    o = OracleNeutFEM(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], case["z_breaks"])
+    o.set_linear_solver(6)
+    for a, t in case["bc"]:
+        o.set_bc(a, t, 0.0)
+    o.get_D()[...] = case["D"]; o.get_SigR()[...] = case["SigR"]; o.get_NSF()[...] = case["NSF"]
+    o.get_Chi()[...] = case["Chi"]; o.get_SigS()[...] = case["SigS"]
+    o.BuildMatrices()
+    return o
+
+
+def algorithmic_bytes(dim, N, nJd):
+    """one Schur apply = 24 N + 40 n_J bytes; a direction pass gets its faces' 40 n_J,d plus an
+    equal share of the 24 N (x read, y write, C diagonal)."""
+    return 24.0 * N / dim + 40.0 * nJd
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+    from neutfem_amd import capi, cases
+    if capi.device_count() <= 0:
+        raise SystemExit("bench.py: no HIP device visible -- the hot path has no CPU fallback")
+    case = cases.iaea3d_resampled(a.n) if a.case == "iaea3d" else cases.synthetic_checkerboard(a.n, a.groups)
+    if world > 1:
+        raise SystemExit("bench.py: multi-GPU slab decomposition is not wired in this build")
+    s = make_solver(case, local)
+    N, ng, dim = s.ne, s.ng, s.dim
+    TOL_FLUX = 1e-4                                             # drivers: set_tol(1e-5,1e-4,1e-4,200,1000)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        s._chk(s.L.nf_synchronize(s.h))
+
+    # warm-up: W untimed outer iterations (also warms caches / clocks); state carries over like the reference
+    if a.warmup > 0:
+        s.set_tol(0.0, TOL_FLUX, 1e-4, a.warmup, 1000)
+        s.solve_keff()
+    s.set_tol(0.0, TOL_FLUX, 1e-4, a.steps, 1000)               # tol_keff = 0 -> exactly K outers
+    s.profile_reset()
+    barrier(); t0 = time.perf_counter()
+    k_timed, n_out = s.solve_keff(profile=True)
+    barrier(); dt = time.perf_counter() - t0
+    assert n_out == a.steps
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    hist = s.history()
+    cg_per_outer = float(hist["cg"].sum()) / a.steps
+
+    # roofline of the dominant kernel (slowest direction pass of the Schur apply)
+    nJd = {0: (s.nx + 1) * s.ny * s.nz, 1: s.nx * (s.ny + 1) * s.nz, 2: s.nx * s.ny * (s.nz + 1)}
+    kern = {0: "k_schur_x<2,NCH,VEC>", 1: "k_schur_s<SEG,1> (y lines)", 2: "k_schur_s<SEG,2> (z lines)"}
+    passes = []
+    for d, nm in enumerate(["schur_x", "schur_y", "schur_z"][:dim]):
+        c, ms = s.profile(nm)
+        if c:
+            passes.append(dict(name=nm, kernel=kern[d], launches=c, avg_ms=ms / c, alg_bytes=algorithmic_bytes(dim, N, nJd[d])))
+    dom = max(passes, key=lambda p: p["avg_ms"])
+    ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
+    ca, cms = s.profile("schur_apply")
+    apply_bytes = 24.0 * N + 40.0 * s.n_J
+    roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
+                    alg_bytes_per_launch=dom["alg_bytes"],
+                    schur_apply=dict(avg_ms=round(cms / max(ca, 1), 4), alg_bytes=apply_bytes,
+                                     achieved=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9, 1),
+                                     frac=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                    passes=[dict(name=p["name"], avg_ms=round(p["avg_ms"], 4),
+                                 achieved=round(p["alg_bytes"] / (p["avg_ms"] * 1e-3) / 1e9, 1)) for p in passes])
+
+    out = dict(metric="outer power-iters/sec (IAEA-3D RT0-P0 k-eigenvalue solve)", value=round(a.steps / dt, 4), unit="outer-iters/s",
+               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
+               scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=case["name"] + ", full Schur path, CG tol 1e-4, Chebyshev", cells=int(N), groups=int(ng),
+                           cg_iters_per_outer=round(cg_per_outer, 1), parallelism=f"1 process per GPU x {world}"),
+               roofline=roofline, keff_after_timed_steps=k_timed)
+
+    if rank == 0 and world == 1:
+        # ---- CPU baseline: bounded sample of the same workload on the host (1 core) -------------------------------
+        if a.cpu_sample_iters > 0:
+            o = make_oracle(case)
+            rhs = np.abs(np.random.default_rng(0).standard_normal(o.n_phi))
+            o.set_tol(0.0, 0.0, 1e-4, 1, a.cpu_sample_iters)    # CG tol 0 -> exactly cpu_sample_iters iterations
+            t1 = time.perf_counter(); _, _, its = o.solve_group(0, rhs); tc = time.perf_counter() - t1
+            per_it = tc / max(its, 1)
+            cpu_outer_s = per_it * cg_per_outer                  # the CG iterations are >99 % of an outer iteration
+            out["cpu_baseline"] = dict(value=round(1.0 / cpu_outer_s, 6), unit="outer-iters/s", cores=1, kind="port",
+                                       sample=f"{its} CG iterations (Schur apply + vector updates + J back-solve) of group 0 on the same "
+                                              f"{case['name']} operator = {tc:.1f} s on one host core; extrapolated with the "
+                                              f"{cg_per_outer:.0f} CG iterations per outer measured in the timed GPU steps",
+                                       sec_per_cg_iteration=round(per_it, 4))
+            del o
+        # ---- untimed: converged k-eff at full size (physics check against the literature value) ---------------
+        if not a.no_converge and a.case == "iaea3d":
+            s.reset_flux()
+            s.set_tol(1e-5, 1e-4, 1e-4, 200, 1000)
+            t1 = time.perf_counter(); kc, nc = s.solve_keff(True, case["coarse_factors"]); tcv = time.perf_counter() - t1
+            out["converged"] = dict(keff=kc, outers=nc, seconds=round(tcv, 2), kref_literature=1.029096,
+                                    pcm_vs_kref=round(1e5 * (1 / 1.029096 - 1 / kc), 2), note="reference driver settings: set_tol(1e-5,1e-4,1e-4,200,1000), coarse init")
+        # ---- small-mesh parity probe against the oracle (same code path, tight tolerances) ---------------------
+        if not a.no_parity and a.case == "iaea3d":
+            small = cases.iaea3d_resampled(38, 19)
+            sp, op = make_solver(small, local), make_oracle(small)
+            tol = (1e-11, 1e-11, 1e-11, 2000, 2000)
+            sp.set_tol(*tol); op.set_tol(*tol)
+            kg, _ = sp.solve_keff(); ko = op.SolveKeff()
+            pg, po = sp.get_phi().ravel(), op.phi_dofs().ravel()
+            out["parity"] = dict(mesh="38x38x19", keff_gpu=kg, keff_oracle=ko, pcm=round(1e5 * abs(kg - ko) / ko, 6),
+                                 flux_rel_l2=float(np.linalg.norm(pg - po) / np.linalg.norm(po)))
+            sp.close()
+    if rank == 0:
+        print(json.dumps(out))
+    s.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -341,9 +341,10 @@ static int launch_s(nf_solver *S, int d, int g, const double *x, double *y, int 
     if (nparts) *nparts = (int)(grid.x * grid.y);
     const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
-    if (SEG == 8) hipLaunchKernelGGL((k_schur_s<8>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg);
-    else if (SEG == 16) hipLaunchKernelGGL((k_schur_s<16>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg);
-    else hipLaunchKernelGGL((k_schur_s<32>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg);
+#define NF_LAUNCH_S(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
+    if (d == 1) { if (SEG == 8) NF_LAUNCH_S(8, 1); else if (SEG == 16) NF_LAUNCH_S(16, 1); else NF_LAUNCH_S(32, 1); }
+    else        { if (SEG == 8) NF_LAUNCH_S(8, 2); else if (SEG == 16) NF_LAUNCH_S(16, 2); else NF_LAUNCH_S(32, 2); }
+#undef NF_LAUNCH_S
     return NF_OK;
 }
 

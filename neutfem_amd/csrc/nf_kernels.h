@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, d
 // Schur apply, y or z direction.  Thread = (ix lane, segment of SEG cells along the line) with
 // the segment held in registers; segment summaries (affine maps) are exchanged through LDS.
 // Always accumulates into y (the x pass ran first).  Grid: (ceil(nx/TX), n_outer).
-template <int SEG>
+// DIR (1 = y, 2 = z) only tags the instantiation so profilers list the two passes separately.
+template <int SEG, int DIR>
 __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ L,
                           const double *__restrict__ DR, const double *__restrict__ D0, int n, long sl,
                           long outer_stride, int nx, int TX, int NSEG, double beta, int last,
