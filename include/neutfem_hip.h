@@ -111,6 +111,11 @@ int nf_profile_reset(nf_handle h);
 /* times `reps` back-to-back Schur applies on group g (random x) with HIP events; average ms per apply */
 int nf_time_schur_apply(nf_handle h, int g, int reps, double *avg_ms);
 
+/* tuning knobs (no reference counterpart): "s_tx" lanes per block row, "s_seg" cells per register segment and
+ * "s_pair" (0/1: two columns per thread, 16-byte accesses) of the y/z line kernels; "cg_batch" CG iterations
+ * launched between host checks of the device-side stop flag.  0 = automatic. */
+int nf_set_option(nf_handle h, const char *key, long value);
+
 /* raw device-memory helpers so callers without torch can drive the *_dev entry points */
 int nf_dev_alloc(nf_handle h, size_t bytes, void **ptr_dev);
 int nf_dev_free(nf_handle h, void *ptr_dev);

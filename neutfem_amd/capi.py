@@ -15,7 +15,7 @@ SYMBOLS = [
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply",
-    "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
+    "nf_set_option", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
 
 
@@ -63,6 +63,7 @@ def load():
     L.nf_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long), dp]
     L.nf_profile_reset.argtypes = [vp]
     L.nf_time_schur_apply.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.nf_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.nf_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.nf_dev_free.argtypes = [vp, vp]
     L.nf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -212,6 +213,8 @@ class HipSolver:
         c, ms = C.c_long(), C.c_double()
         self._chk(self.L.nf_profile_get(self.h, name.encode(), C.byref(c), C.byref(ms)))
         return c.value, ms.value
+
+    def set_option(self, key, value): self._chk(self.L.nf_set_option(self.h, key.encode(), int(value)))
 
     def profile_reset(self): self._chk(self.L.nf_profile_reset(self.h))
 

@@ -69,6 +69,7 @@ struct nf_solver {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
+    int opt_s_tx = 0, opt_s_seg = 0, opt_s_pair = 0;      // tuning overrides (nf_set_option)
 };
 
 const char *nf_last_error(void) { return g_err.c_str(); }
@@ -156,7 +157,7 @@ int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int 
     if (rc == NF_OK) rc = dalloc(&S->d_p, S->N);
     if (rc == NF_OK) rc = dalloc(&S->d_q, S->N);
     // partial sums: the Schur passes write one partial per block
-    long maxblocks = std::max<long>(RED_GRID, std::max(S->nlines[0], (long)(((S->nx + 15) / 16)) * std::max(S->ny, S->nz)) + 16);
+    long maxblocks = std::max<long>(RED_GRID, std::max(S->nlines[0], (long)(((S->nx + 7) / 8)) * std::max(S->ny, S->nz)) + 16);
     S->partial_stride = maxblocks;
     if (rc == NF_OK) rc = dalloc(&S->d_partials, (size_t)maxblocks * 3);
     if (rc == NF_OK) rc = dalloc(&S->d_cg, 1);
@@ -330,21 +331,31 @@ static int launch_s(nf_solver *S, int d, int g, const double *x, double *y, int 
     const long nxy = (long)S->nx * S->ny;
     const long sl = d == 1 ? S->nx : nxy, ostride = d == 1 ? nxy : S->nx;
     const int nouter = d == 1 ? S->nz : S->ny;
-    int SEG = n <= 64 ? 8 : (n <= 1024 ? 16 : 32);
+    const bool pair = S->opt_s_pair && (S->nx % 2 == 0);          // two columns per thread, double2 accesses
+    int SEG = S->opt_s_seg ? S->opt_s_seg : (pair ? (n <= 256 ? 4 : 8) : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
     int NSEG = (n + SEG - 1) / SEG;
-    if (NSEG > 64) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit (2048 cells)", n);
-    int TX = 64;
-    while (TX > 16 && TX * NSEG > 1024) TX >>= 1;
+    if (NSEG > 128) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit", n);
+    const int cols = pair ? (S->nx + 1) / 2 : S->nx;              // thread columns needed
+    int TX = S->opt_s_tx ? S->opt_s_tx : 64;
+    while (TX > 8 && TX * NSEG > 1024) TX >>= 1;
     if (TX * NSEG > 1024) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than 1024 threads per block", n);
-    while (TX > 16 && TX / 2 >= S->nx) TX >>= 1;                 // narrow meshes
-    dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter), block((unsigned)(TX * NSEG));
+    while (TX > 8 && TX / 2 >= cols) TX >>= 1;                    // narrow meshes
+    dim3 grid((unsigned)((cols + TX - 1) / TX), (unsigned)nouter), block((unsigned)(TX * NSEG));
     if (nparts) *nparts = (int)(grid.x * grid.y);
-    const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
+    if (pair) {
+        const size_t lds = (size_t)(4 * TX * NSEG + TX) * sizeof(double2) + 16 * sizeof(double);
+#define NF_LAUNCH_S2(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s2<SEGV, DIRV>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
+        if (d == 1) { if (SEG == 4) NF_LAUNCH_S2(4, 1); else if (SEG == 8) NF_LAUNCH_S2(8, 1); else if (SEG == 16) NF_LAUNCH_S2(16, 1); else return fail(NF_ERR_ARG, "bad s_seg"); }
+        else        { if (SEG == 4) NF_LAUNCH_S2(4, 2); else if (SEG == 8) NF_LAUNCH_S2(8, 2); else if (SEG == 16) NF_LAUNCH_S2(16, 2); else return fail(NF_ERR_ARG, "bad s_seg"); }
+#undef NF_LAUNCH_S2
+    } else {
+        const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
 #define NF_LAUNCH_S(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
-    if (d == 1) { if (SEG == 8) NF_LAUNCH_S(8, 1); else if (SEG == 16) NF_LAUNCH_S(16, 1); else NF_LAUNCH_S(32, 1); }
-    else        { if (SEG == 8) NF_LAUNCH_S(8, 2); else if (SEG == 16) NF_LAUNCH_S(16, 2); else NF_LAUNCH_S(32, 2); }
+        if (d == 1) { if (SEG == 4) NF_LAUNCH_S(4, 1); else if (SEG == 8) NF_LAUNCH_S(8, 1); else if (SEG == 16) NF_LAUNCH_S(16, 1); else if (SEG == 32) NF_LAUNCH_S(32, 1); else return fail(NF_ERR_ARG, "bad s_seg"); }
+        else        { if (SEG == 4) NF_LAUNCH_S(4, 2); else if (SEG == 8) NF_LAUNCH_S(8, 2); else if (SEG == 16) NF_LAUNCH_S(16, 2); else if (SEG == 32) NF_LAUNCH_S(32, 2); else return fail(NF_ERR_ARG, "bad s_seg"); }
 #undef NF_LAUNCH_S
+    }
     return NF_OK;
 }
 
@@ -688,6 +699,10 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
     HIPCHK(hipSetDevice(S->device));
     hipLaunchKernelGGL(k_fill_pattern, dim3(grid_for(S->N)), dim3(256), 0, S->stream, S->d_p, S->N);
     NFCHK(schur_apply(S, g, S->d_p, S->d_q, nullptr, nullptr, nullptr));   // warm-up
+    S->profile = true;
+    for (int i = 0; i < std::min(reps, 8); ++i) NFCHK(schur_apply(S, g, S->d_p, S->d_q, nullptr, nullptr, nullptr));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    prof_collect(S); S->profile = false;
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     HIPCHK(hipEventRecord(a, S->stream));
     for (int i = 0; i < reps; ++i) NFCHK(schur_apply(S, g, S->d_p, S->d_q, nullptr, nullptr, nullptr));
@@ -696,6 +711,17 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
     float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *avg_ms = ms / reps;
+    return NF_OK;
+}
+
+int nf_set_option(nf_handle S, const char *key, long value)
+{
+    if (!S || !key) return fail(NF_ERR_ARG, "nf_set_option: bad arguments");
+    if (!strcmp(key, "s_tx")) S->opt_s_tx = (int)value;
+    else if (!strcmp(key, "s_seg")) S->opt_s_seg = (int)value;
+    else if (!strcmp(key, "s_pair")) S->opt_s_pair = (int)value;
+    else if (!strcmp(key, "cg_batch")) S->cg_batch = (int)value;
+    else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
 }
 

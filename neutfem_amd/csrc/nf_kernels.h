@@ -399,6 +399,103 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
     }
 }
 
+// Same algorithm, two adjacent x-columns (two independent lines) per thread: every access is a 16-byte
+// double2, so one wave instruction moves TXP*16 contiguous bytes per segment row (1 KiB at TXP = 64).
+// Requires nx even.  Thread = (ix pair, segment); TXP pairs per block row.
+template <int SEG, int DIR>
+__global__ void k_schur_s2(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ L,
+                           const double *__restrict__ DR, const double *__restrict__ D0, int n, long sl,
+                           long outer_stride, int nx, int TXP, int NSEG, double beta, int last,
+                           double *__restrict__ partials, const CgScalars *__restrict__ cg)
+{
+    extern __shared__ double sm[];
+    if (cg && cg->done) return;
+    const int T = TXP * NSEG;
+    double2 *sA = reinterpret_cast<double2 *>(sm), *sB = sA + T, *sA2 = sA + 2 * T, *sB2 = sA + 3 * T, *sZ0 = sA + 4 * T;
+    double *sred = reinterpret_cast<double *>(sZ0 + TXP);
+    const int tid = threadIdx.x, ixl = tid % TXP, seg = tid / TXP;
+    const int ix = (blockIdx.x * TXP + ixl) * 2;
+    const bool valid = ix < nx;
+    const long base = (long)blockIdx.y * outer_stride + ix;
+    const int c0 = seg * SEG;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];
+#pragma unroll
+    for (int i = 0; i <= SEG; ++i) {
+        const int c = c0 + i; const bool ok = valid && c < n;
+        const long a = base + (long)c * sl;
+        xv[i] = ok ? *reinterpret_cast<const double2 *>(x + a) : zero2;
+        Lv[i] = ok ? *reinterpret_cast<const double2 *>(L + a) : zero2;
+        if (i < SEG) {
+            Rv[i] = ok ? *reinterpret_cast<const double2 *>(DR + a) : zero2;
+            yo[i] = ok ? *reinterpret_cast<const double2 *>(y + a) : zero2;
+        }
+    }
+    double2 dinv_s = zero2;
+    if (valid && c0 < n)
+        dinv_s = c0 == 0 ? *reinterpret_cast<const double2 *>(D0 + (long)blockIdx.y * nx + ix)
+                         : *reinterpret_cast<const double2 *>(DR + base + (long)(c0 - 1) * sl);
+    double2 t[SEG];
+    double2 P = make_double2(1.0, 1.0), lz = zero2;
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+        t[i].x = beta * (xv[i].x - xv[i + 1].x); t[i].y = beta * (xv[i].y - xv[i + 1].y);
+        lz.x = t[i].x - Lv[i].x * lz.x; lz.y = t[i].y - Lv[i].y * lz.y;
+        P.x = -Lv[i].x * P.x; P.y = -Lv[i].y * P.y;
+    }
+    sA[seg * TXP + ixl] = P; sB[seg * TXP + ixl] = lz;
+    if (seg == 0) sZ0[ixl] = make_double2(-beta * xv[0].x, -beta * xv[0].y);
+    __syncthreads();
+    double2 z = sZ0[ixl];
+    for (int s = 0; s < seg; ++s) {
+        const double2 a = sA[s * TXP + ixl], b = sB[s * TXP + ixl];
+        z.x = a.x * z.x + b.x; z.y = a.y * z.y + b.y;
+    }
+    const double2 zin = z;
+    double2 w[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+        z.x = t[i].x - Lv[i].x * z.x; z.y = t[i].y - Lv[i].y * z.y;
+        w[i].x = z.x * Rv[i].x; w[i].y = z.y * Rv[i].y;
+    }
+    double2 Q = make_double2(1.0, 1.0), lu = zero2;
+#pragma unroll
+    for (int i = SEG - 1; i >= 0; --i) {
+        lu.x = w[i].x - Lv[i + 1].x * lu.x; lu.y = w[i].y - Lv[i + 1].y * lu.y;
+        Q.x = -Lv[i + 1].x * Q.x; Q.y = -Lv[i + 1].y * Q.y;
+    }
+    sA2[seg * TXP + ixl] = Q; sB2[seg * TXP + ixl] = lu;
+    __syncthreads();
+    double2 u = zero2;
+    for (int s = NSEG - 1; s > seg; --s) {
+        const double2 a = sA2[s * TXP + ixl], b = sB2[s * TXP + ixl];
+        u.x = a.x * u.x + b.x; u.y = a.y * u.y + b.y;
+    }
+#pragma unroll
+    for (int i = SEG - 1; i >= 0; --i) {
+        u.x = w[i].x - Lv[i + 1].x * u.x; u.y = w[i].y - Lv[i + 1].y * u.y;
+        w[i] = u;
+    }
+    double2 ulo;
+    ulo.x = zin.x * dinv_s.x - Lv[0].x * w[0].x; ulo.y = zin.y * dinv_s.y - Lv[0].y * w[0].y;
+    double dot = 0.0;
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+        const double2 lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
+        double2 yv;
+        yv.x = yo[i].x + beta * (w[i].x - lo.x); yv.y = yo[i].y + beta * (w[i].y - lo.y);
+        const int c = c0 + i;
+        if (valid && c < n) {
+            *reinterpret_cast<double2 *>(y + base + (long)c * sl) = yv;
+            dot += xv[i].x * yv.x + xv[i].y * yv.y;
+        }
+    }
+    if (last && partials) {
+        const double s = block_sum(dot, sred);
+        if (tid == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // CG vector kernels (src/solvers.cpp:577-631).  Fixed grids, grid-stride loops.
 __global__ __launch_bounds__(256) void k_cg_init(const double *__restrict__ rhs, double *__restrict__ x,
