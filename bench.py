@@ -124,11 +124,22 @@ def main():
         if c:
             passes.append(dict(name=nm, kernel=kern[d], launches=c, avg_ms=ms / c, alg_bytes=algorithmic_bytes(dim, N, nJd[d])))
     dom = max(passes, key=lambda p: p["avg_ms"])
+    # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    # command, gfx950 x2 read correction; profiles/r01_pmc_traffic_256cube.json).  Per-cell figure x cells of this run.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_256cube.json")) as f:
+            pmc = json.load(f)["kernels"]
+        key = {"schur_x": "k_schur_x<2, 2, true>", "schur_y": "k_schur_s<8, 1>", "schur_z": "k_schur_s<8, 2>"}[dom["name"]]
+        if a.n == 256 and a.case == "iaea3d":
+            traffic = round(pmc[key]["hbm_bytes_per_cell"] * N)
+    except Exception:
+        traffic = None
     ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
     ca, cms = s.profile("schur_apply")
     apply_bytes = 24.0 * N + 40.0 * s.n_J
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
                     alg_bytes_per_launch=dom["alg_bytes"],
                     schur_apply=dict(avg_ms=round(cms / max(ca, 1), 4), alg_bytes=apply_bytes,
                                      achieved=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9, 1),

@@ -1,0 +1,98 @@
+"""CPU-only tests of the drop-in boundary: the C-ABI library loads and exports every symbol declared in
+include/neutfem_hip.h, fails loudly without a GPU, and the pybind11 module mirrors the reference's Python
+surface (src/wrapper.cpp).  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "neutfem_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nf_[A-Za-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from neutfem_amd import capi
+    L = capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), f"libneutfem_hip.so does not export {name}"
+    assert sorted(capi.SYMBOLS) == declared, "neutfem_amd/capi.py and include/neutfem_hip.h disagree"
+
+
+def test_no_cpu_fallback():
+    from neutfem_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.HipSolver(0, 0, 2, np.linspace(0, 1, 5), np.linspace(0, 1, 5), np.array([0.0]))
+    L = capi.load()
+    assert L.nf_build(None) != 0 and b"null" in L.nf_last_error()
+
+
+def test_product_does_not_touch_the_oracle():
+    """the oracle is test infrastructure: nothing under neutfem_amd/ or include/ may reference it"""
+    for base in ("neutfem_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "nf_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_pybind_surface_matches_reference():
+    import neutfem_amd
+    neutfem_amd.install_compat()
+    import neutfem._neutfem_eigen as m
+    # enums and values (include/NeutFEM.hpp:51-91, include/solvers.hpp:176-190)
+    assert [int(getattr(m.BCType, n)) for n in ("DIRICHLET", "NEUMANN", "MIRROR", "ROBIN", "PERIODIC")] == [0, 1, 2, 3, 4]
+    assert int(m.BoundaryID.LEFT_3D) == 3 and int(m.BoundaryID.TOP_3D) == 5 and int(m.BoundaryID.BOTTOM_2D) == 4
+    assert int(m.LinearSolverType.BICGSTAB) == 6 and int(m.LinearSolverType.LCG) == 9
+    assert int(m.VerbosityLevel.NORMAL) == 2 and not hasattr(m.VerbosityLevel, "LIGHT")
+    methods = ["set_bc", "set_robin_coefficients", "set_linear_solver", "set_tol", "set_verbosity", "set_cmfd_relaxation",
+               "apply_quarter_symmetry", "add_refl", "set_refl", "clean_refl", "BuildMatrices", "SolveKeff", "SolveAdjoint",
+               "SolveSubcritical", "SolveCoarse", "build_diagonal_cache", "initialize_cmfd", "ExportVTK", "ExportFluxVTK",
+               "ExportXSVTK", "get_D", "get_SRC", "get_SigR", "get_NSF", "get_KSF", "get_Chi", "get_SigS", "get_flux",
+               "get_flux_adj", "reset_flux", "GetNumElements", "GetNumGroups", "GetDimension", "GetLastKeff",
+               "GetLastKeffAdjoint", "GetSolverName", "project_flux", "project_power", "zoom_resolved"]
+    for name in methods:                                       # src/wrapper.cpp:336-1065
+        assert hasattr(m.NeutFEM, name), name
+    s = m.NeutFEM(0, 2, np.linspace(0, 30, 4), np.linspace(0, 20, 3), np.linspace(0, 10, 6))
+    s.set_verbosity(m.VerbosityLevel.SILENT)
+    assert s.get_D().shape == (2, 5, 2, 3) and s.get_SigS().shape == (2, 2, 5, 2, 3) and s.get_flux().shape == (2, 5, 2, 3)
+    assert (s.get_D() == 1.0).all() and (s.get_SigR() == 0.01).all() and (s.get_Chi()[0] == 1).all() and (s.get_Chi()[1] == 0).all()
+    s.get_D()[1, 4, 1, 2] = 7.0                                # writable zero-copy views, a new view per call
+    assert s.get_D()[1, 4, 1, 2] == 7.0 and s.get_D().base is not None
+    assert s.GetNumElements() == 30 and s.GetDimension() == 3 and s.GetNumGroups() == 1      # reference bug kept
+    assert s.GetSolverName() == "BiCGSTAB" and s.GetLastKeff() == 1.0
+    assert s.add_refl(np.zeros(1), np.zeros(1), np.zeros(1)) == 0
+    p1 = m.NeutFEM(1, 1, 1, np.linspace(0, 3, 4), np.linspace(0, 2, 3), np.array([0.0]))
+    assert p1.GetNumGroups() == 4 and p1.get_flux().shape == (1, 2, 3)       # P1: DOF-0 copy
+    unstable = m.NeutFEM(0, 1, 1, np.linspace(0, 3, 4), np.array([0.0]), np.array([0.0]))   # RT0-P1 forced to RT0-P0
+    assert unstable.GetNumGroups() == 1
+    with pytest.raises(RuntimeError):
+        s.SolveKeff()                                          # BuildMatrices not called
+    with pytest.raises(RuntimeError):
+        s.SolveAdjoint()
+    if m.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            s.BuildMatrices()
+
+
+def test_case_generators():
+    from neutfem_amd import cases
+    c = cases.iaea3d_resampled(19)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "inputs_iaea3d_1x1.npz"))
+    for k in ("D", "SigR", "NSF", "Chi", "SigS"):
+        assert np.array_equal(c[k], z[k])                      # n = 19 reproduces the driver's own 1x1 mesh
+    c = cases.iaea3d_resampled(38, 19, z_range=(4, 9))
+    assert c["D"].shape == (2, 5, 38, 38) and len(c["z_breaks"]) == 6
+    k = cases.synthetic_checkerboard(32, 4)
+    assert k["SigS"].shape == (4, 4, 32, 32, 32) and k["SigS"][2, 3].max() == 0.002 and k["NSF"][:, 0, 0, 16].max() == 0.0

@@ -1,0 +1,153 @@
+"""CPU-only tests of the oracle (test infrastructure): closed forms, the independent scipy restatement
+(oracle/ref_scipy.py) and the committed golden vectors.  `pytest -m "not gpu"` runs these in this container."""
+import numpy as np
+import pytest
+
+from helpers import TEST_TOL, load_golden, load_inputs, make_oracle, rel_l2, synthetic_inputs
+from oracle.oracle import OracleNeutFEM
+from oracle.ref_scipy import RefScipy
+
+
+def _mesh(dim, n=(5, 4, 3), h=(1.3, 0.7, 2.1)):
+    xb = np.arange(n[0] + 1) * h[0]
+    yb = np.arange(n[1] + 1) * h[1] if dim >= 2 else np.array([0.0])
+    zb = np.arange(n[2] + 1) * h[2] if dim == 3 else np.array([0.0])
+    return xb, yb, zb
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_rt0_local_matrices_closed_form(dim):
+    """A_loc = (1/D) factor_d 2^(d-1) [[2/3,1/3],[1/3,2/3]], B = -+2^(d-1), C = Sigma V (src/FEM.cpp:748-953)"""
+    xb, yb, zb = _mesh(dim)
+    o = OracleNeutFEM(0, 0, 1, xb, yb, zb)
+    D, Sig = 1.7, 0.23
+    A, B, C = o.local_matrices(0, D, Sig)
+    hx, hy, hz = 1.3, (0.7 if dim >= 2 else 1.0), (2.1 if dim == 3 else 1.0)
+    fac = {1: [hx / 2], 2: [hy / hx, hx / hy], 3: [2 * hx / (hy * hz), 2 * hy / (hx * hz), 2 * hz / (hx * hy)]}[dim]
+    p2 = 2 ** (dim - 1)
+    for d in range(dim):
+        blk = A[2 * d:2 * d + 2, 2 * d:2 * d + 2]
+        np.testing.assert_allclose(blk, fac[d] / D * p2 * np.array([[2 / 3, 1 / 3], [1 / 3, 2 / 3]]), rtol=1e-14)
+        np.testing.assert_allclose(B[0, 2 * d:2 * d + 2], [-p2, p2], rtol=1e-14)
+    assert abs(A).sum() == pytest.approx(sum(abs(A[2 * d:2 * d + 2, 2 * d:2 * d + 2]).sum() for d in range(dim)))
+    np.testing.assert_allclose(C, [[Sig * hx * hy * hz]], rtol=1e-14)
+
+
+def test_rt1_p1_2d_unit_tables():
+    """known answers of SURVEY 8a: chain [L0,R0,b0] = [[4/3,2/3,4/3],[2/3,4/3,4/3],[4/3,4/3,32/15]], mode 1 = 1/3 of it,
+    B rows and C-hat = diag(4,4/3,4/3,4/9) on the reference square (hx = hy = 2 -> factors 1, detJ 1)"""
+    o = OracleNeutFEM(1, 1, 1, np.array([0.0, 2.0, 4.0]), np.array([0.0, 2.0, 4.0]), np.array([0.0]))
+    A, B, C = o.local_matrices(0, 1.0, 1.0)
+    # local x order: [L0, L1, R0, R1, b0, b1]
+    m0 = np.array([[4 / 3, 2 / 3, 4 / 3], [2 / 3, 4 / 3, 4 / 3], [4 / 3, 4 / 3, 32 / 15]])
+    np.testing.assert_allclose(A[np.ix_([0, 2, 4], [0, 2, 4])], m0, atol=1e-14)
+    np.testing.assert_allclose(A[np.ix_([1, 3, 5], [1, 3, 5])], m0 / 3, atol=1e-14)
+    np.testing.assert_allclose(A[np.ix_([0, 2, 4], [1, 3, 5])], 0, atol=1e-14)       # modes decouple
+    np.testing.assert_allclose(A[:6, 6:], 0, atol=1e-14)                              # directions decouple
+    np.testing.assert_allclose(np.diag(C), [4, 4 / 3, 4 / 3, 4 / 9], rtol=1e-14)
+    np.testing.assert_allclose(C - np.diag(np.diag(C)), 0, atol=1e-14)
+    np.testing.assert_allclose(B[0, :6], [-2, 0, 2, 0, 0, 0], atol=1e-14)
+    np.testing.assert_allclose(B[1, :6], [0, 0, 0, 0, -8 / 3, 0], atol=1e-14)
+    np.testing.assert_allclose(B[2, :6], [0, -2 / 3, 0, 2 / 3, 0, 0], atol=1e-14)
+    np.testing.assert_allclose(B[3, :6], [0, 0, 0, 0, 0, -8 / 9], atol=1e-14)
+
+
+def test_dof_numbering():
+    """src/FEM.cpp:264-334,955-999: x-face (iz*ny+iy)*(nx+1)+ix, y-face (iz*(ny+1)+iy)*nx+ix, z-face (iz*ny+iy)*nx+ix"""
+    xb, yb, zb = _mesh(3)
+    o = OracleNeutFEM(0, 0, 1, xb, yb, zb)
+    nx, ny, nz = 5, 4, 3
+    ix, iy, iz = 2, 3, 1
+    nJx, nJy = (nx + 1) * ny * nz, nx * (ny + 1) * nz
+    exp = [(iz * ny + iy) * (nx + 1) + ix, (iz * ny + iy) * (nx + 1) + ix + 1,
+           nJx + (iz * (ny + 1) + iy) * nx + ix, nJx + (iz * (ny + 1) + iy + 1) * nx + ix,
+           nJx + nJy + (iz * ny + iy) * nx + ix, nJx + nJy + ((iz + 1) * ny + iy) * nx + ix]
+    assert o.global_J_indices(ix, iy, iz).tolist() == exp
+    o1 = OracleNeutFEM(1, 1, 1, xb, yb, np.array([0.0]))
+    assert o1.n_J == 2 * ((nx + 1) * ny + nx * (ny + 1)) + nx * ny * 2 * 2 and o1.n_phi == 4 * nx * ny
+
+
+def _pair(inp, rt, p):
+    o = make_oracle(inp, rt, p)
+    r = RefScipy(rt, p, int(inp["ng"]), inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    for a, t in zip(inp["bc_attr"], inp["bc_type"]):
+        r.bc[int(a)] = int(t)
+    ng = int(inp["ng"])
+    r.D = inp["D"].reshape(ng, -1); r.SigR = inp["SigR"].reshape(ng, -1); r.NSF = inp["NSF"].reshape(ng, -1)
+    r.Chi = inp["Chi"].reshape(ng, -1); r.SigS = inp["SigS"].reshape(ng, ng, -1)
+    r.build()
+    return o, r
+
+
+@pytest.mark.parametrize("shape,rt,p", [((9, 1, 1), 0, 0), ((9, 1, 1), 2, 1), ((8, 7, 1), 0, 0), ((8, 7, 1), 1, 1), ((6, 5, 1), 2, 2),
+                                        ((6, 5, 1), 2, 0), ((6, 5, 4), 0, 0), ((4, 3, 3), 1, 1), ((3, 3, 2), 2, 2)])
+def test_oracle_vs_scipy_operator_and_solve(shape, rt, p):
+    """C oracle (banded chains, matrix-free) vs explicit sparse assembly + SuperLU: Schur apply and k-eff."""
+    inp = synthetic_inputs(*shape, ng=2, seed=sum(shape) + rt, dirichlet=(1, 2, 3, 5))
+    o, r = _pair(inp, rt, p)
+    x = np.random.default_rng(0).standard_normal(o.n_phi)
+    for g in range(2):
+        assert rel_l2(o.schur_apply(g, x), r.schur_apply(g, x)) < 1e-12
+    tol = (1e-9, 1e-9, 1e-9, 400, 2000)
+    o.set_tol(*tol); r.set_tol(*tol)
+    ko = o.SolveKeff(); kr = r.solve_keff()
+    assert abs(ko - kr) / kr < 1e-9
+    assert rel_l2(o.phi_dofs().ravel(), r.phi) < 1e-8
+
+
+def test_oracle_vs_scipy_iaea2d_with_coarse_init():
+    inp = load_inputs("iaea2d")
+    inp = {k: (v[..., ::2, ::2] if k in ("D", "SigR", "NSF", "Chi", "SigS") else v) for k, v in inp.items()}   # 19x19 assemblies
+    inp["x_breaks"] = inp["x_breaks"][::2]; inp["y_breaks"] = inp["y_breaks"][::2]
+    inp = {k: np.ascontiguousarray(v) if isinstance(v, np.ndarray) and v.ndim else v for k, v in inp.items()}
+    for rt, p in ((0, 0), (1, 1)):
+        o, r = _pair(inp, rt, p)
+        o.set_tol(*TEST_TOL); r.set_tol(*TEST_TOL)
+        ko = o.SolveKeff(False, []); kr = r.solve_keff()
+        h = o.history()
+        assert abs(ko - kr) < 1e-11 and h["n_outer"] == len(r.hist)
+        assert np.array_equal(h["cg"].astype(int), np.array([x[3] for x in r.hist]))
+        assert rel_l2(o.phi_dofs().ravel(), r.phi) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["iaea2d", "iaea3d_1x1", "koeberg2d", "biblis2d", "zion2d"])
+def test_oracle_reproduces_golden(name):
+    """the committed golden vectors are what the oracle computes today (regression pin)"""
+    inp, gold = load_inputs(name), load_golden(name)
+    for run in gold["runs"]:
+        if name == "iaea3d_1x1" and run["tol"][0] < 1e-6:
+            continue                                            # 124 outers: covered by the GPU suite
+        o = make_oracle(inp, run["rt"], run["p"])
+        o.set_tol(*run["tol"])
+        k = o.SolveKeff(run["coarse"], [int(v) for v in inp["coarse_factors"]] if run["coarse"] else [], run["diag"])
+        assert abs(k - run["keff"]) < 1e-12
+        assert o.info("last_outer") == run["n_outer"]
+        phi = o.phi_dofs().ravel()
+        assert rel_l2(phi[::run["phi_stride"]], run["phi_samples"]) < 1e-12
+
+
+def test_literature_keff_sanity():
+    """physics anchor (the only numbers the reference itself pins): RT1-P1 on the 10 cm IAEA-2D mesh lands within
+    10 pcm of the literature k_ref = 1.029585 (tests/iaea2d/iaea2d.py:39); KOEBERG RT1-P1 within 10 pcm of 1.007954"""
+    for name, kref in (("iaea2d", 1.029585), ("koeberg2d", 1.007954)):
+        run = [r for r in load_golden(name)["runs"] if r["rt"] == 1 and r["p"] == 1][0]
+        assert abs(1e5 * (1 / kref - 1 / run["keff"])) < 10.0
+
+
+def test_reference_quirks():
+    inp = load_inputs("iaea2d")
+    o = make_oracle(inp)
+    o.set_tol(*TEST_TOL)
+    o.SolveKeff()
+    h = o.history()
+    assert h["k"][0] == 1.0                      # k is not updated on outer 0 (src/NeutFEM.cpp:1774)
+    k1 = o.GetLastKeff(); n1 = h["n_outer"]
+    o.SolveKeff()                                # warm start: has_valid_keff_ (src/NeutFEM.cpp:1662)
+    assert o.history()["n_outer"] < n1 and abs(o.GetLastKeff() - k1) < 1e-4
+    # coarse factors that do not divide the mesh: (1.0, current flux) (src/NeutFEM.cpp:2402-2407)
+    k, phi = o.SolveCoarse([3, 3, 1])
+    assert k == 1.0 and np.array_equal(phi, o.phi_dofs().ravel())
+    # 2D Piola factor quirk: factor_x = hy/hx (src/FEM.cpp:803-804)
+    q = OracleNeutFEM(0, 0, 1, np.array([0.0, 2.0, 4.0]), np.array([0.0, 3.0, 6.0]), np.array([0.0]))
+    A, _, _ = q.local_matrices(0, 1.0, 0.0)
+    assert A[0, 0] == pytest.approx((3.0 / 2.0) * 2 * 2 / 3) and A[2, 2] == pytest.approx((2.0 / 3.0) * 2 * 2 / 3)
