@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-sample-iters", type=int, default=6, help="CG iterations timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed converged solve (k-eff, pcm)")
     ap.add_argument("--no-parity", action="store_true", help="skip the small-mesh GPU-vs-oracle parity probe")
+    ap.add_argument("--loopback-slabs", type=int, default=1, help="z-slabs per process (>1: exercise the slab path on one GPU)")
     return ap.parse_args()
 
 
@@ -73,31 +74,66 @@ def algorithmic_bytes(dim, N, nJd):
     return 24.0 * N / dim + 40.0 * nJd
 
 
+def split_planes(nz, parts):
+    """contiguous z-plane ranges, as even as possible"""
+    cuts = [round(i * nz / parts) for i in range(parts + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(parts)]
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dist = dist_mod
-    from neutfem_amd import capi, cases
+    from neutfem_amd import capi, cases                       # loads libneutfem_hip.so (and with it the ROCm HIP runtime) first
     if capi.device_count() <= 0:
         raise SystemExit("bench.py: no HIP device visible -- the hot path has no CPU fallback")
-    case = cases.iaea3d_resampled(a.n) if a.case == "iaea3d" else cases.synthetic_checkerboard(a.n, a.groups)
+    dist = None
     if world > 1:
-        raise SystemExit("bench.py: multi-GPU slab decomposition is not wired in this build")
-    s = make_solver(case, local)
-    N, ng, dim = s.ne, s.ng, s.dim
+        # torch.distributed is plumbing only: rendezvous, barrier and the max-over-ranks of the timing (gloo, CPU).
+        # The data path (interface planes, dot products) goes over RCCL inside libneutfem_hip.so.
+        import torch
+        import torch.distributed as dist_mod
+        dist_mod.init_process_group("gloo")
+        dist = dist_mod
+    nz = a.n
+    slabs_total = world * a.loopback_slabs
+    if slabs_total > 1:
+        # every rank builds only its own z-planes of the XS
+        allp = split_planes(nz, slabs_total)
+        mine = allp[rank * a.loopback_slabs:(rank + 1) * a.loopback_slabs]
+        k0, k1 = mine[0][0], mine[-1][1]
+        case = cases.iaea3d_resampled(a.n, z_range=(k0, k1)) if a.case == "iaea3d" else None
+        if case is None:
+            raise SystemExit("bench.py: the slab-decomposed run supports --case iaea3d")
+        zb_full = np.linspace(0.0, 380.0, nz + 1)
+        s = capi.HipTeam(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], zb_full, mine, device=local,
+                         below=rank > 0, above=rank < world - 1)
+        s.set_linear_solver(6)
+        for at, ty in case["bc"]:
+            s.set_bc(at, ty)
+        s.upload_xs_global(case["D"], case["SigR"], case["NSF"], case["Chi"], case["SigS"], k_offset=k0)
+        s.build()
+        if world > 1:
+            import torch
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(capi.HipTeam.unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(idt, 0)
+            s.comm_init(bytes(idt.numpy().tobytes()), world, rank)
+        head = s.head
+        N_local = sum(x.ne for x in s.slabs); ng, dim = head.ng, head.dim
+        N = a.n * a.n * nz
+    else:
+        case = cases.iaea3d_resampled(a.n) if a.case == "iaea3d" else cases.synthetic_checkerboard(a.n, a.groups)
+        s = make_solver(case, local)
+        head = s
+        N, ng, dim = s.ne, s.ng, s.dim
     TOL_FLUX = 1e-4                                             # drivers: set_tol(1e-5,1e-4,1e-4,200,1000)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        s._chk(s.L.nf_synchronize(s.h))
+        head._chk(head.L.nf_synchronize(head.h))               # stream + device synchronize
 
     # warm-up: W untimed outer iterations (also warms caches / clocks); state carries over like the reference
     if a.warmup > 0:
@@ -111,18 +147,25 @@ def main():
     assert n_out == a.steps
     if dist is not None:
         import torch
-        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     hist = s.history()
     cg_per_outer = float(hist["cg"].sum()) / a.steps
 
     # roofline of the dominant kernel (slowest direction pass of the Schur apply)
-    nJd = {0: (s.nx + 1) * s.ny * s.nz, 1: s.nx * (s.ny + 1) * s.nz, 2: s.nx * s.ny * (s.nz + 1)}
+    # per-launch figures refer to what ONE rank's launches process (its own planes)
+    if slabs_total > 1:
+        nzl = max(x.nz for x in s.slabs); nxl, nyl = head.nx, head.ny
+        Nl = nxl * nyl * nzl
+    else:
+        nzl, nxl, nyl, Nl = s.nz, s.nx, s.ny, N
+    nJd = {0: (nxl + 1) * nyl * nzl, 1: nxl * (nyl + 1) * nzl, 2: nxl * nyl * (nzl + 1)}
     kern = {0: "k_schur_x<2,NCH,VEC>", 1: "k_schur_s<SEG,1> (y lines)", 2: "k_schur_s<SEG,2> (z lines)"}
     passes = []
     for d, nm in enumerate(["schur_x", "schur_y", "schur_z"][:dim]):
         c, ms = s.profile(nm)
         if c:
-            passes.append(dict(name=nm, kernel=kern[d], launches=c, avg_ms=ms / c, alg_bytes=algorithmic_bytes(dim, N, nJd[d])))
+            per = a.loopback_slabs                                  # launches per timed pass (one per local slab)
+            passes.append(dict(name=nm, kernel=kern[d], launches=c * per, avg_ms=ms / c / per, alg_bytes=algorithmic_bytes(dim, Nl, nJd[d])))
     dom = max(passes, key=lambda p: p["avg_ms"])
     # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     # command, gfx950 x2 read correction; profiles/r01_pmc_traffic_256cube.json).  Per-cell figure x cells of this run.
@@ -131,13 +174,13 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_256cube.json")) as f:
             pmc = json.load(f)["kernels"]
         key = {"schur_x": "k_schur_x<2, 2, true>", "schur_y": "k_schur_s<8, 1>", "schur_z": "k_schur_s<8, 2>"}[dom["name"]]
-        if a.n == 256 and a.case == "iaea3d":
+        if a.n == 256 and a.case == "iaea3d" and slabs_total == 1:
             traffic = round(pmc[key]["hbm_bytes_per_cell"] * N)
     except Exception:
         traffic = None
     ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
     ca, cms = s.profile("schur_apply")
-    apply_bytes = 24.0 * N + 40.0 * s.n_J
+    apply_bytes = (24.0 * Nl + 40.0 * sum(nJd[d] for d in range(dim))) * a.loopback_slabs
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
                     alg_bytes_per_launch=dom["alg_bytes"],
@@ -150,11 +193,13 @@ def main():
     out = dict(metric="outer power-iters/sec (IAEA-3D RT0-P0 k-eigenvalue solve)", value=round(a.steps / dt, 4), unit="outer-iters/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload=case["name"] + ", full Schur path, CG tol 1e-4, Chebyshev", cells=int(N), groups=int(ng),
-                           cg_iters_per_outer=round(cg_per_outer, 1), parallelism=f"1 process per GPU x {world}"),
+               config=dict(workload=(f"IAEA-3D resampled {a.n}x{a.n}x{nz} RT0-P0 2g" if a.case == "iaea3d" else case["name"]) +
+                           ", full Schur path, CG tol 1e-4, Chebyshev", cells=int(N), groups=int(ng),
+                           cg_iters_per_outer=round(cg_per_outer, 1),
+                           parallelism=f"{world} process(es) x {a.loopback_slabs} z-slab(s) each; RCCL: interface planes + scalar all-reduces"),
                roofline=roofline, keff_after_timed_steps=k_timed)
 
-    if rank == 0 and world == 1:
+    if rank == 0 and slabs_total == 1:
         # ---- CPU baseline: bounded sample of the same workload on the host (1 core) -------------------------------
         if a.cpu_sample_iters > 0:
             o = make_oracle(case)

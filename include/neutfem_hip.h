@@ -39,8 +39,25 @@ int nf_create(int rt_order, int p_order, int ng,
               int device, nf_handle *out);
 int nf_destroy(nf_handle h);
 
+/* ---- multi-GPU: z-slab decomposition (no reference counterpart; the reference is single-process) ------------
+ * A slab is an nf_handle over the z-planes [k0,k1) of the global mesh: same x/y breaks, zb_slab = the slab's
+ * own k1-k0+1 z-breaks, interface_below/above = 1 where another slab continues the mesh (that side is then not
+ * a domain boundary).  Slabs living in one process on one device are chained with nf_link_slabs (bottom to top);
+ * slabs of other processes are reached through RCCL: rank 0 calls nf_comm_unique_id, the 128 bytes are broadcast
+ * by the launcher (torch.distributed / MPI / a file), every rank calls nf_comm_init.  Rank r must hold the slabs
+ * just above rank r-1's.  After that nf_solve_keff / nf_time_schur_apply on any slab of the team run the whole
+ * team; nf_set_phi / nf_get_phi / nf_upload_xs / nf_build stay per slab. */
+int nf_create_slab(int rt_order, int p_order, int ng,
+                   int nxb, const double *xb_host, int nyb, const double *yb_host, int nzb_slab, const double *zb_slab_host,
+                   int interface_below, int interface_above, int device, nf_handle *out);
+int nf_link_slabs(nf_handle *handles, int n);
+int nf_comm_unique_id(void *id128_host);
+int nf_comm_init(nf_handle h, const void *id128_host, int nranks, int rank);
+/* Schur apply on every local slab: x_dev[i] / y_dev[i] = device vectors of local slab i */
+int nf_team_schur_apply(nf_handle h, int g, const double *const *x_dev, double *const *y_dev);
+
 /* sizes: "dim","nx","ny","nz","ne","ng","n_phi","n_J","n_loc","last_outer","last_cg_total",
- * "coarse_outer","device" ; returns -1 for an unknown key */
+ * "coarse_outer","device","n_local_slabs","n_ranks","rank" ; returns -1 for an unknown key */
 long nf_info(nf_handle h, const char *key);
 
 /* NeutFEM::SetBC (src/NeutFEM.cpp:337-345): attr per BoundaryID (include/NeutFEM.hpp:73-91).
@@ -105,7 +122,7 @@ int nf_get_warm_state(nf_handle h, int *has_valid_keff, double *last_keff);
 int nf_get_history(nf_handle h, double *k, double *dk, double *dphi, int *cg, int cap_outer);
 
 /* profiling: kernels timed with HIP events on the solver's stream (opts.profile / nf_time_schur_apply).
- * name in {"schur_x","schur_y","schur_z","schur_apply"}: number of timed launches and their total ms. */
+ * name in {"schur_x","schur_y","schur_z","schur_apply","schur_z1"}: number of timed launches and their total ms. */
 int nf_profile_get(nf_handle h, const char *name, long *count, double *total_ms);
 int nf_profile_reset(nf_handle h);
 /* times `reps` back-to-back Schur applies on group g (random x) with HIP events; average ms per apply */

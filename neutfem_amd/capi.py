@@ -11,7 +11,8 @@ import numpy as np
 from . import lib_path
 
 SYMBOLS = [
-    "nf_last_error", "nf_device_count", "nf_create", "nf_destroy", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
+    "nf_last_error", "nf_device_count", "nf_create", "nf_destroy", "nf_create_slab", "nf_link_slabs", "nf_comm_unique_id",
+    "nf_comm_init", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply",
@@ -42,6 +43,11 @@ def load():
     L.nf_last_error.restype = C.c_char_p
     L.nf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.POINTER(vp)]
     L.nf_destroy.argtypes = [vp]
+    L.nf_create_slab.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.nf_link_slabs.argtypes = [C.POINTER(vp), C.c_int]
+    L.nf_comm_unique_id.argtypes = [vp]
+    L.nf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.nf_team_schur_apply.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.nf_info.restype = C.c_long
     L.nf_info.argtypes = [vp, C.c_char_p]
     L.nf_set_bc.argtypes = [vp, C.c_int, C.c_int]
@@ -108,12 +114,16 @@ class DeviceVector:
 class HipSolver:
     """One nf_handle.  Method names follow the C ABI; see include/neutfem_hip.h for reference citations."""
 
-    def __init__(self, rt_order, p_order, ng, x_breaks, y_breaks, z_breaks, device=0):
+    def __init__(self, rt_order, p_order, ng, x_breaks, y_breaks, z_breaks, device=0, interface_below=False, interface_above=False):
         self.L = load()
         xb, yb, zb = (np.ascontiguousarray(a, dtype=np.float64) for a in (x_breaks, y_breaks, z_breaks))
         h = C.c_void_p()
         self.h = None
-        self._chk(self.L.nf_create(rt_order, p_order, ng, len(xb), _dp(xb), len(yb), _dp(yb), len(zb), _dp(zb), device, C.byref(h)))
+        if interface_below or interface_above:      # z_breaks are the slab's own breaks
+            self._chk(self.L.nf_create_slab(rt_order, p_order, ng, len(xb), _dp(xb), len(yb), _dp(yb), len(zb), _dp(zb),
+                                            int(interface_below), int(interface_above), device, C.byref(h)))
+        else:
+            self._chk(self.L.nf_create(rt_order, p_order, ng, len(xb), _dp(xb), len(yb), _dp(yb), len(zb), _dp(zb), device, C.byref(h)))
         self.h = h
         for key in ("dim", "nx", "ny", "nz", "ne", "ng", "n_phi", "n_J"):
             setattr(self, key, self.L.nf_info(h, key.encode()))
@@ -224,3 +234,92 @@ class HipSolver:
 
 def device_count():
     return load().nf_device_count()
+
+
+class HipTeam:
+    """The z-slabs of one global mesh held by THIS process (include/neutfem_hip.h, multi-GPU section).
+
+    planes = [(k0, k1), ...] consecutive z-plane ranges of the local slabs (bottom to top);
+    below / above = True if another process holds the slab below the first / above the last local slab.
+    With one process and several ranges this is the single-GPU loopback used by the tests."""
+
+    def __init__(self, rt_order, p_order, ng, x_breaks, y_breaks, z_breaks, planes, device=0, below=False, above=False):
+        zb = np.asarray(z_breaks, dtype=np.float64)
+        self.planes = [tuple(p) for p in planes]
+        self.slabs = []
+        for i, (k0, k1) in enumerate(self.planes):
+            lo = below if i == 0 else True
+            hi = above if i == len(self.planes) - 1 else True
+            self.slabs.append(HipSolver(rt_order, p_order, ng, x_breaks, y_breaks, zb[k0:k1 + 1], device, lo, hi))
+        self.L = self.slabs[0].L
+        self.ng = ng
+        if len(self.slabs) > 1:
+            arr = (C.c_void_p * len(self.slabs))(*[s.h for s in self.slabs])
+            self.slabs[0]._chk(self.L.nf_link_slabs(arr, len(self.slabs)))
+        self.head = self.slabs[0]
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
+
+    def comm_init(self, id_bytes, nranks, rank):
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        self.head._chk(self.L.nf_comm_init(self.head.h, buf, nranks, rank))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        L = load()
+        if L.nf_comm_unique_id(buf) != 0:
+            raise RuntimeError(L.nf_last_error().decode())
+        return buf.raw
+
+    def set_bc(self, attr, t):
+        for s in self.slabs: s.set_bc(attr, t)
+
+    def set_tol(self, *a):
+        for s in self.slabs: s.set_tol(*a)
+
+    def set_linear_solver(self, t):
+        for s in self.slabs: s.set_linear_solver(t)
+
+    def upload_xs_local(self, arrays_per_slab):
+        for s, a in zip(self.slabs, arrays_per_slab): s.upload_xs(*a)
+
+    def upload_xs_global(self, D, SigR, NSF, Chi, SigS, k_offset=0):
+        """global (.., nz, ny, nx) arrays; k_offset = global plane index of array plane 0"""
+        for s, (k0, k1) in zip(self.slabs, self.planes):
+            sl = slice(k0 - k_offset, k1 - k_offset)
+            s.upload_xs(D[:, sl], SigR[:, sl], NSF[:, sl], Chi[:, sl], SigS[:, :, sl])
+
+    def build(self):
+        for s in self.slabs: s.build()
+
+    def solve_keff(self, profile=False):
+        return self.head.solve_keff(profile=profile)
+
+    def history(self): return self.head.history()
+    def profile(self, name): return self.head.profile(name)
+    def profile_reset(self): self.head.profile_reset()
+    def time_schur_apply(self, g, reps): return self.head.time_schur_apply(g, reps)
+    def synchronize(self): self.head._chk(self.L.nf_synchronize(self.head.h))
+
+    def get_phi_local(self):
+        """(ng, local planes, ny, nx)"""
+        return np.concatenate([s.get_phi().reshape(self.ng, s.nz, s.ny, s.nx) for s in self.slabs], axis=1)
+
+    def set_phi_local(self, phi):
+        k = 0
+        for s in self.slabs:
+            s.set_phi(np.ascontiguousarray(phi[:, k:k + s.nz])); k += s.nz
+
+    def schur_apply(self, g, x_local):
+        """x_local: (local planes, ny, nx) -> S x on the local planes (loopback: the whole mesh)"""
+        xs, ys, k = [], [], 0
+        for s in self.slabs:
+            xs.append(s.vector().upload(np.ascontiguousarray(x_local[k:k + s.nz]).ravel())); ys.append(s.vector()); k += s.nz
+        xa = (C.c_void_p * len(xs))(*[v.ptr for v in xs]); ya = (C.c_void_p * len(ys))(*[v.ptr for v in ys])
+        self.head._chk(self.L.nf_team_schur_apply(self.head.h, g, xa, ya))
+        out = np.concatenate([v.download() for v in ys])
+        for v in xs + ys: v.free()
+        return out.reshape(x_local.shape)

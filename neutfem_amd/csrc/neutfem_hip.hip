@@ -3,8 +3,17 @@
 // Host logic mirrors the reference's control flow (NeutFEM::SolveKeff / SolveCoarse /
 // SchurSolver::Solve) while every vector stays resident in HBM; per outer iteration the host
 // reads back 4 doubles, per CG solve one small struct every few iterations.
+//
+// Multi-GPU: the mesh is cut into z-slabs.  A "team" is the set of slabs of one global problem that
+// live in this process (one per GPU in production; several on one GPU in the loopback used for
+// testing) plus an RCCL communicator to the slabs of the other processes.  Every phase of the solve
+// loops over the local slabs; the only data-path communication is (i) one plane of fp64 per slab
+// interface per Schur apply (partition method for the z-line solves) and (ii) all-reduces of 1-3
+// scalars, all enqueued on the team's stream -- the host never waits for them.
 #include "../../include/neutfem_hip.h"
 #include "nf_kernels.h"
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -28,13 +37,79 @@ static int fail(int code, const char *fmt, ...)
 #define NFCHK(x) do { int r_ = (x); if (r_ != NF_OK) return r_; } while (0)
 
 static const int RED_GRID = 1024;          // fixed grid of the streaming/reduction kernels
+static const int MAX_LOCAL_SLABS = 16;
 
 struct ProfSlot { long count = 0; double ms = 0.0; };
 
-struct nf_solver {
+// ---- RCCL, resolved lazily with dlopen so that single-GPU use never loads it -------------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+static const int NCCL_DOUBLE = 8, NCCL_SUM = 0;       // ncclFloat64 / ncclSum in rccl.h
+#define NCCLCHK(x) do { int r_ = (x); if (r_ != 0) return fail(NF_ERR_HIP, "%s failed: %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); } while (0)
+
+static int rccl_load()
+{
+    if (g_rccl.lib) return NF_OK;
+    // the ROCm install this library was built against first; symbols are taken from THIS handle only (dlsym), so a
+    // second RCCL copy that a framework may have mapped (e.g. the one bundled with PyTorch) is never mixed in
+    const char *env = getenv("NEUTFEM_RCCL_LIB");
+    const char *names[] = { env ? env : "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so" };
+    for (const char *n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.lib) break; }
+    if (!g_rccl.lib) return fail(NF_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+#define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.lib, name); if (!g_rccl.field) return fail(NF_ERR_HIP, "librccl.so lacks %s", name); } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return NF_OK;
+}
+
+struct nf_solver;
+struct nf_team {
+    std::vector<nf_solver *> slabs;
     int device = 0;
     hipStream_t stream = nullptr;
-    // mesh
+    int nproc = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    bool rccl_reduce = false;       // scalar reductions go through ncclAllReduce (nproc > 1, or forced for testing)
+    double *d_partials = nullptr; long partial_stride = 0, slab_cap = 0;
+    CgScalars *d_cg = nullptr;
+    double *d_out = nullptr;        // 4 doubles read by the host each outer
+    double *d_red = nullptr;        // 4 doubles: process-local sums awaiting the all-reduce
+    bool linked_ready = false;      // separator diagonals exchanged
+    std::vector<int> last_its;
+    // stats of the last SolveKeff
+    int last_outer = 0, coarse_outer = 0; long last_cg_total = 0;
+    std::vector<double> hist_k, hist_dk, hist_dphi; std::vector<int> hist_cg;
+    int has_valid_keff = 0; double last_keff = 1.0;
+    // profiling
+    bool profile = false;
+    std::map<std::string, ProfSlot> prof;
+    struct Ev { hipEvent_t a, b; int slot; };
+    std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+    int cg_batch = 0;
+    int opt_s_tx = 0, opt_s_seg = 0, opt_s_pair = 0;      // tuning overrides (nf_set_option)
+};
+
+struct nf_solver {
+    int device = 0;
+    nf_team *team = nullptr;
+    int slab_index = 0;
+    int if_lo = 0, if_hi = 0;                            // interface with the slab below / above (z)
+    // mesh (of this slab)
     int dim = 1, nx = 1, ny = 1, nz = 1, ng = 1, k = 0, m = 0;
     long N = 0, nJ = 0, nJx = 0, nJy = 0, nJz = 0;
     std::vector<double> xb, yb, zb, hx, hy, hz;
@@ -50,26 +125,15 @@ struct nf_solver {
     double *d_L[3] = {nullptr, nullptr, nullptr}, *d_DR[3] = {nullptr, nullptr, nullptr}, *d_D0[3] = {nullptr, nullptr, nullptr};
     long nlines[3] = {0, 0, 0};
     double *d_Sinv = nullptr;
+    // slab interfaces (partition method for the z lines), all per z-line
+    double *d_alo = nullptr, *d_ahi = nullptr, *d_hlo = nullptr, *d_hhi = nullptr, *d_gfl = nullptr;   // ng * nlines[2]
+    double *d_sinv_lo = nullptr, *d_sinv_hi = nullptr;  // ng * nlines[2]
+    double *d_clo = nullptr, *d_chi = nullptr, *d_rlo = nullptr, *d_rhi = nullptr, *d_ulo = nullptr, *d_uhi = nullptr;
     // state
     double *d_phi = nullptr, *d_raw = nullptr;          // current iterate / raw group solutions, ng*N
     double *d_p0 = nullptr, *d_p1 = nullptr;            // Chebyshev history
     double *d_tf = nullptr, *d_rhs = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
-    double *d_partials = nullptr; long partial_stride = 0;
-    CgScalars *d_cg = nullptr;
-    double *d_out = nullptr;                            // 4 doubles
     bool raw_valid = false, raw_is_diag = false;
-    int has_valid_keff = 0; double last_keff = 1.0;
-    // stats
-    int last_outer = 0, coarse_outer = 0; long last_cg_total = 0;
-    std::vector<double> hist_k, hist_dk, hist_dphi; std::vector<int> hist_cg;
-    std::vector<int> last_its;
-    // profiling
-    bool profile = false;
-    std::map<std::string, ProfSlot> prof;
-    struct Ev { hipEvent_t a, b; int slot; };
-    std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
-    int cg_batch = 0;
-    int opt_s_tx = 0, opt_s_seg = 0, opt_s_pair = 0;      // tuning overrides (nf_set_option)
 };
 
 const char *nf_last_error(void) { return g_err.c_str(); }
@@ -89,7 +153,7 @@ template <class T> static int dalloc(T **p, size_t n)
 }
 template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
-static const char *SLOT_NAMES[4] = { "schur_x", "schur_y", "schur_z", "schur_apply" };
+static const char *SLOT_NAMES[5] = { "schur_x", "schur_y", "schur_z", "schur_apply", "schur_z1" };
 
 static Geom make_geom(const nf_solver *S)
 {
@@ -105,11 +169,54 @@ static Geom make_geom(const nf_solver *S)
         G.dir_lo[d] = S->bc_set[lo] && S->bc_type[lo] == NF_BC_DIRICHLET;
         G.dir_hi[d] = S->bc_set[hi] && S->bc_type[hi] == NF_BC_DIRICHLET;
     }
+    if (S->if_lo) G.dir_lo[2] = 0;             // a slab interface is not a domain boundary
+    if (S->if_hi) G.dir_hi[2] = 0;
     return G;
 }
 
-int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int nyb, const double *yb, int nzb,
-              const double *zb, int device, nf_handle *out)
+static int grid_for(long n, int block = 256, int cap = RED_GRID)
+{
+    long g = (n + block - 1) / block; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g;
+}
+
+// ---- team management ---------------------------------------------------------------------------
+static long slab_partial_need(const nf_solver *S)
+{
+    return std::max<long>(RED_GRID, std::max(S->nlines[0], (long)((S->nx + 7) / 8) * std::max(S->ny, S->nz))) + 16;
+}
+static int team_alloc(nf_team *T)
+{
+    long cap = 0;
+    for (auto *S : T->slabs) cap = std::max(cap, slab_partial_need(S));
+    T->slab_cap = cap; T->partial_stride = cap * (long)T->slabs.size();
+    NFCHK(dalloc(&T->d_partials, (size_t)T->partial_stride * 3));
+    if (!T->d_cg) NFCHK(dalloc(&T->d_cg, 1));
+    if (!T->d_out) NFCHK(dalloc(&T->d_out, 4));
+    if (!T->d_red) NFCHK(dalloc(&T->d_red, 4));
+    T->last_its.assign(64, 0);
+    return NF_OK;
+}
+static void team_free(nf_team *T)
+{
+    if (!T) return;
+    (void)hipSetDevice(T->device);
+    if (T->stream) (void)hipStreamSynchronize(T->stream);
+    for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
+    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red);
+    if (T->stream) (void)hipStreamDestroy(T->stream);
+    delete T;
+}
+static PartSegs segs_for(const nf_team *T, const std::vector<int> &counts)
+{
+    PartSegs ps; ps.n = (int)T->slabs.size();
+    for (int i = 0; i < ps.n; ++i) { ps.off[i] = (int)(i * T->slab_cap); ps.cnt[i] = counts[i]; }
+    return ps;
+}
+
+static int create_impl(int rt_order, int p_order, int ng, int nxb, const double *xb, int nyb, const double *yb, int nzb,
+                       const double *zb, int if_lo, int if_hi, int device, nf_handle *out)
 {
     if (!out || !xb || nxb < 2 || ng < 1 || ng > 64) return fail(NF_ERR_ARG, "nf_create: bad arguments");
     int k = std::min(rt_order, 2), m = std::min(p_order, 2);
@@ -121,12 +228,13 @@ int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int 
     if (device < 0 || device >= ndev) return fail(NF_ERR_ARG, "nf_create: device %d out of range (%d devices)", device, ndev);
     HIPCHK(hipSetDevice(device));
     nf_solver *S = new nf_solver();
-    S->device = device; S->k = k; S->m = m; S->ng = ng;
+    S->device = device; S->k = k; S->m = m; S->ng = ng; S->if_lo = if_lo; S->if_hi = if_hi;
     S->xb.assign(xb, xb + nxb);
     if (nyb > 1) S->yb.assign(yb, yb + nyb); else S->yb.assign(1, nyb == 1 && yb ? yb[0] : 0.0);
     if (nzb > 1) S->zb.assign(zb, zb + nzb); else S->zb.assign(1, nzb == 1 && zb ? zb[0] : 0.0);
     S->nx = nxb - 1; S->ny = nyb > 1 ? nyb - 1 : 1; S->nz = nzb > 1 ? nzb - 1 : 1;
     S->dim = S->nz > 1 ? 3 : (S->ny > 1 ? 2 : 1);               // src/FEM.cpp:33-35
+    if ((if_lo || if_hi) && (S->dim != 3 || S->nz < 3)) { delete S; return fail(NF_ERR_ARG, "a slab needs a 3D mesh with at least 3 z-planes"); }
     S->N = (long)S->nx * S->ny * S->nz;
     S->hx.resize(S->nx); S->hy.assign(S->ny, 1.0); S->hz.assign(S->nz, 1.0);
     for (int i = 0; i < S->nx; ++i) S->hx[i] = xb[i + 1] - xb[i];
@@ -137,7 +245,9 @@ int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int 
     S->nJz = S->dim == 3 ? (long)S->nx * S->ny * (S->nz + 1) : 0;
     S->nJ = S->nJx + S->nJy + S->nJz;
     S->nlines[0] = (long)S->ny * S->nz; S->nlines[1] = (long)S->nx * S->nz; S->nlines[2] = (long)S->nx * S->ny;
-    const char *cb = getenv("NEUTFEM_CG_BATCH"); S->cg_batch = cb ? atoi(cb) : 0;
+    nf_team *T = new nf_team();
+    T->device = device; T->slabs.push_back(S); S->team = T; S->slab_index = 0;
+    const char *cb = getenv("NEUTFEM_CG_BATCH"); T->cg_batch = cb ? atoi(cb) : 0;
     *out = S;
     int rc = NF_OK;
     auto up = [&](double **d, const std::vector<double> &h) {
@@ -146,7 +256,7 @@ int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int 
         if (rc == NF_OK && hipMemcpy(*d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(NF_ERR_HIP, "nf_create: upload failed");
     };
-    if (hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(NF_ERR_HIP, "hipStreamCreate failed");
+    if (hipStreamCreateWithFlags(&T->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(NF_ERR_HIP, "hipStreamCreate failed");
     up(&S->d_hx, S->hx); up(&S->d_hy, S->hy); up(&S->d_hz, S->hz); up(&S->d_xb, S->xb); up(&S->d_yb, S->yb); up(&S->d_zb, S->zb);
     const size_t NN = (size_t)S->N * ng;
     if (rc == NF_OK) rc = dalloc(&S->d_phi, NN);
@@ -156,46 +266,108 @@ int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int 
     if (rc == NF_OK) rc = dalloc(&S->d_r, S->N);
     if (rc == NF_OK) rc = dalloc(&S->d_p, S->N);
     if (rc == NF_OK) rc = dalloc(&S->d_q, S->N);
-    // partial sums: the Schur passes write one partial per block
-    long maxblocks = std::max<long>(RED_GRID, std::max(S->nlines[0], (long)(((S->nx + 7) / 8)) * std::max(S->ny, S->nz)) + 16);
-    S->partial_stride = maxblocks;
-    if (rc == NF_OK) rc = dalloc(&S->d_partials, (size_t)maxblocks * 3);
-    if (rc == NF_OK) rc = dalloc(&S->d_cg, 1);
-    if (rc == NF_OK) rc = dalloc(&S->d_out, 4);
+    if (rc == NF_OK && (if_lo || if_hi)) {
+        const size_t nl = (size_t)S->nlines[2];
+        double **arrs[] = { &S->d_clo, &S->d_chi, &S->d_rlo, &S->d_rhi, &S->d_ulo, &S->d_uhi };
+        for (auto a : arrs) if (rc == NF_OK) { rc = dalloc(a, nl); if (rc == NF_OK) (void)hipMemset(*a, 0, nl * sizeof(double)); }
+    }
+    if (rc == NF_OK) rc = team_alloc(T);
     if (rc != NF_OK) { nf_destroy(S); *out = nullptr; return rc; }
     S->d_SigS.assign((size_t)ng * ng, nullptr); S->d_Ms.assign((size_t)ng * ng, nullptr);
-    S->last_its.assign(ng, 0);
     return nf_reset_flux(S);
+}
+
+int nf_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int nyb, const double *yb, int nzb,
+              const double *zb, int device, nf_handle *out)
+{
+    return create_impl(rt_order, p_order, ng, nxb, xb, nyb, yb, nzb, zb, 0, 0, device, out);
+}
+int nf_create_slab(int rt_order, int p_order, int ng, int nxb, const double *xb, int nyb, const double *yb, int nzb,
+                   const double *zb_slab, int interface_below, int interface_above, int device, nf_handle *out)
+{
+    return create_impl(rt_order, p_order, ng, nxb, xb, nyb, yb, nzb, zb_slab, interface_below ? 1 : 0, interface_above ? 1 : 0, device, out);
 }
 
 int nf_destroy(nf_handle S)
 {
     if (!S) return NF_OK;
     (void)hipSetDevice(S->device);
-    if (S->stream) (void)hipStreamSynchronize(S->stream);
+    nf_team *T = S->team;
+    if (T && T->stream) (void)hipStreamSynchronize(T->stream);
     dfree(S->d_hx); dfree(S->d_hy); dfree(S->d_hz); dfree(S->d_xb); dfree(S->d_yb); dfree(S->d_zb);
     dfree(S->d_D); dfree(S->d_SigR); dfree(S->d_NSF); dfree(S->d_Chi);
     for (auto &p : S->d_SigS) dfree(p);
     for (auto &p : S->d_Ms) dfree(p);
     dfree(S->d_Cd); dfree(S->d_Mf); dfree(S->d_Sinv);
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
+    dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
+    dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
     dfree(S->d_phi); dfree(S->d_raw); dfree(S->d_p0); dfree(S->d_p1);
     dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q);
-    dfree(S->d_partials); dfree(S->d_cg); dfree(S->d_out);
-    for (auto &e : S->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (auto &e : S->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (S->stream) (void)hipStreamDestroy(S->stream);
+    if (T) {
+        T->slabs.erase(std::remove(T->slabs.begin(), T->slabs.end(), S), T->slabs.end());
+        for (size_t i = 0; i < T->slabs.size(); ++i) T->slabs[i]->slab_index = (int)i;
+        if (T->slabs.empty()) team_free(T);
+    }
     delete S;
+    return NF_OK;
+}
+
+// link n slabs (ordered bottom to top, same device, adjacent ones sharing an interface) into one team
+int nf_link_slabs(nf_handle *handles, int n)
+{
+    if (!handles || n < 1 || n > MAX_LOCAL_SLABS) return fail(NF_ERR_ARG, "nf_link_slabs: 1..%d slabs", MAX_LOCAL_SLABS);
+    nf_solver *S0 = handles[0];
+    if (!S0) return fail(NF_ERR_ARG, "nf_link_slabs: null handle");
+    HIPCHK(hipSetDevice(S0->device));
+    for (int i = 0; i < n; ++i) {
+        nf_solver *S = handles[i];
+        if (!S || S->team->slabs.size() != 1) return fail(NF_ERR_STATE, "nf_link_slabs: handle %d is null or already linked", i);
+        if (S->device != S0->device || S->nx != S0->nx || S->ny != S0->ny || S->ng != S0->ng)
+            return fail(NF_ERR_ARG, "nf_link_slabs: slab %d does not match slab 0 (device, nx, ny, groups)", i);
+        if (i > 0 && (!S->if_lo || !handles[i - 1]->if_hi)) return fail(NF_ERR_ARG, "nf_link_slabs: slabs %d/%d lack the shared interface flag", i - 1, i);
+    }
+    nf_team *T = S0->team;
+    for (int i = 1; i < n; ++i) {
+        nf_solver *S = handles[i];
+        team_free(S->team);
+        S->team = T; S->slab_index = i; T->slabs.push_back(S);
+    }
+    T->linked_ready = false;
+    return team_alloc(T);
+}
+
+int nf_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(NF_ERR_ARG, "nf_comm_unique_id: null buffer");
+    NFCHK(rccl_load());
+    ncclUniqueId id; NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return NF_OK;
+}
+int nf_comm_init(nf_handle S, const void *id128, int nranks, int rank)
+{
+    if (!S || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(NF_ERR_ARG, "nf_comm_init: bad arguments");
+    nf_team *T = S->team;
+    const bool force = getenv("NEUTFEM_FORCE_RCCL") != nullptr;   // 1-rank communicator: exercises the RCCL reduce path on one GPU
+    if (nranks == 1 && !force) { T->nproc = 1; T->rank = 0; return NF_OK; }
+    NFCHK(rccl_load());
+    HIPCHK(hipSetDevice(T->device));
+    ncclUniqueId id; memcpy(&id, id128, sizeof id);
+    NCCLCHK(g_rccl.CommInitRank(&T->comm, nranks, id, rank));
+    T->nproc = nranks; T->rank = rank; T->linked_ready = false; T->rccl_reduce = true;
     return NF_OK;
 }
 
 long nf_info(nf_handle S, const char *key)
 {
     if (!S || !key) return -1;
+    nf_team *T = S->team;
 #define K(s, v) if (!strcmp(key, s)) return (long)(v)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
-    K("n_phi", S->N); K("n_J", S->nJ); K("n_loc", 1); K("last_outer", S->last_outer);
-    K("last_cg_total", S->last_cg_total); K("coarse_outer", S->coarse_outer); K("device", S->device);
+    K("n_phi", S->N); K("n_J", S->nJ); K("n_loc", 1); K("last_outer", T->last_outer);
+    K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
+    K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
 #undef K
     return -1;
 }
@@ -211,29 +383,25 @@ int nf_upload_xs(nf_handle S, const double *D, const double *SigR, const double 
 {
     if (!S || !D || !SigR || !NSF || !Chi || !SigS) return fail(NF_ERR_ARG, "nf_upload_xs: null pointer");
     HIPCHK(hipSetDevice(S->device));
+    hipStream_t st = S->team->stream;
     const size_t NN = (size_t)S->N * S->ng, B = NN * sizeof(double);
     NFCHK(dalloc(&S->d_D, NN)); NFCHK(dalloc(&S->d_SigR, NN)); NFCHK(dalloc(&S->d_NSF, NN)); NFCHK(dalloc(&S->d_Chi, NN));
-    HIPCHK(hipMemcpyAsync(S->d_D, D, B, hipMemcpyHostToDevice, S->stream));
-    HIPCHK(hipMemcpyAsync(S->d_SigR, SigR, B, hipMemcpyHostToDevice, S->stream));
-    HIPCHK(hipMemcpyAsync(S->d_NSF, NSF, B, hipMemcpyHostToDevice, S->stream));
-    HIPCHK(hipMemcpyAsync(S->d_Chi, Chi, B, hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipMemcpyAsync(S->d_D, D, B, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(S->d_SigR, SigR, B, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(S->d_NSF, NSF, B, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(S->d_Chi, Chi, B, hipMemcpyHostToDevice, st));
     const int ng = S->ng;
     for (int i = 0; i < ng * ng; ++i) {
         const double *blk = SigS + (size_t)i * S->N;
         bool nz = false;                                          // src/NeutFEM.cpp:1265 : |sigs| > 1e-14
         for (long e = 0; e < S->N; ++e) if (std::fabs(blk[e]) > 1e-14) { nz = true; break; }
-        if (!nz) { dfree(S->d_SigS[i]); continue; }
+        if (!nz) { dfree(S->d_SigS[i]); continue; }              // an empty block adds exact zeros: skipping it is equivalent (:1722)
         NFCHK(dalloc(&S->d_SigS[i], S->N));
-        HIPCHK(hipMemcpyAsync(S->d_SigS[i], blk, S->N * sizeof(double), hipMemcpyHostToDevice, S->stream));
+        HIPCHK(hipMemcpyAsync(S->d_SigS[i], blk, S->N * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipStreamSynchronize(st));
     S->xs_uploaded = true; S->built = false;
     return NF_OK;
-}
-
-static int grid_for(long n, int block = 256, int cap = RED_GRID)
-{
-    long g = (n + block - 1) / block; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g;
 }
 
 int nf_build(nf_handle S)
@@ -241,55 +409,154 @@ int nf_build(nf_handle S)
     if (!S) return fail(NF_ERR_ARG, "nf_build: null handle");
     if (!S->xs_uploaded) return fail(NF_ERR_STATE, "nf_build: call nf_upload_xs first");
     HIPCHK(hipSetDevice(S->device));
+    hipStream_t st = S->team->stream;
     const int ng = S->ng; const long N = S->N; const size_t NN = (size_t)N * ng;
     NFCHK(dalloc(&S->d_Cd, NN)); NFCHK(dalloc(&S->d_Mf, NN));
     for (int d = 0; d < S->dim; ++d) {
         NFCHK(dalloc(&S->d_L[d], NN)); NFCHK(dalloc(&S->d_DR[d], NN)); NFCHK(dalloc(&S->d_D0[d], (size_t)S->nlines[d] * ng));
     }
+    const bool slab = S->if_lo || S->if_hi;
+    if (slab) {
+        const size_t nl = (size_t)S->nlines[2] * ng;
+        NFCHK(dalloc(&S->d_alo, nl)); NFCHK(dalloc(&S->d_ahi, nl)); NFCHK(dalloc(&S->d_hlo, nl)); NFCHK(dalloc(&S->d_hhi, nl));
+        NFCHK(dalloc(&S->d_gfl, nl)); NFCHK(dalloc(&S->d_sinv_lo, nl)); NFCHK(dalloc(&S->d_sinv_hi, nl));
+    }
     Geom G = make_geom(S);
     const int gN = grid_for(N, 256, 65535);
     for (int g = 0; g < ng; ++g) {
-        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, S->stream, S->d_SigR + g * N, S->d_Cd + g * N, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 0);
-        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, S->stream, S->d_NSF + g * N, S->d_Mf + g * N, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1);
+        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigR + g * N, S->d_Cd + g * N, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 0);
+        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_NSF + g * N, S->d_Mf + g * N, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1);
         for (int gp = 0; gp < ng; ++gp) {
             const int i = g * ng + gp;
             if (!S->d_SigS[i]) { dfree(S->d_Ms[i]); continue; }
             NFCHK(dalloc(&S->d_Ms[i], N));
-            hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, S->stream, S->d_SigS[i], S->d_Ms[i], S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1);
+            hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigS[i], S->d_Ms[i], S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1);
         }
         for (int d = 0; d < S->dim; ++d) {
             const long nl = S->nlines[d];
-            hipLaunchKernelGGL(k_factor_lines, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, S->stream, G, d, S->d_D + g * N,
-                               S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * nl, nl);
+            SlabOut so = { nullptr, nullptr, nullptr, nullptr, nullptr };
+            int lo = 0, hi = 0;
+            if (d == 2 && slab) {
+                lo = S->if_lo; hi = S->if_hi;
+                so.alo = S->d_alo + g * nl; so.ahi = S->d_ahi + g * nl; so.hlo = S->d_hlo + g * nl; so.hhi = S->d_hhi + g * nl; so.gfl = S->d_gfl + g * nl;
+            }
+            hipLaunchKernelGGL(k_factor_lines, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, G, d, S->d_D + g * N,
+                               S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * nl, nl, lo, hi, so);
         }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipStreamSynchronize(st));
     S->built = true; S->diag_valid = false;                       // src/NeutFEM.cpp:454-456
+    S->team->linked_ready = false;
     return NF_OK;
 }
 
 // ---- profiling helpers -----------------------------------------------------------------------
-static void prof_begin(nf_solver *S, int slot, hipEvent_t *a, hipEvent_t *b)
+static void prof_begin(nf_team *T, int slot, hipEvent_t *a, hipEvent_t *b)
 {
-    if (S->ev_free.empty()) {
-        hipEvent_t x, y; (void)hipEventCreate(&x); (void)hipEventCreate(&y); S->ev_free.push_back({x, y});
+    if (T->ev_free.empty()) {
+        hipEvent_t x, y; (void)hipEventCreate(&x); (void)hipEventCreate(&y); T->ev_free.push_back({x, y});
     }
-    auto pr = S->ev_free.back(); S->ev_free.pop_back();
+    auto pr = T->ev_free.back(); T->ev_free.pop_back();
     *a = pr.first; *b = pr.second;
-    (void)hipEventRecord(*a, S->stream);
-    S->ev_pending.push_back({*a, *b, slot});
+    (void)hipEventRecord(*a, T->stream);
+    T->ev_pending.push_back({*a, *b, slot});
 }
-static void prof_collect(nf_solver *S)
+static void prof_collect(nf_team *T)
 {
-    for (auto &e : S->ev_pending) {
+    for (auto &e : T->ev_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            auto &sl = S->prof[SLOT_NAMES[e.slot]]; sl.count += 1; sl.ms += ms;
+            auto &sl = T->prof[SLOT_NAMES[e.slot]]; sl.count += 1; sl.ms += ms;
         }
-        S->ev_free.push_back({e.a, e.b});
+        T->ev_free.push_back({e.a, e.b});
     }
-    S->ev_pending.clear();
+    T->ev_pending.clear();
+}
+
+// ---- communication between slabs -----------------------------------------------------------------
+// exchange one plane per interface: own c_hi goes up (becomes the upper slab's r_lo), own c_lo goes down.
+// which = 0: the per-apply contributions (d_clo/d_chi -> d_rlo/d_rhi); which = 1: the separator-diagonal halves of
+// group g (d_hlo/d_hhi -> d_rlo/d_rhi, build time).
+static int exchange_planes(nf_team *T, int which, int g)
+{
+    const int ns = (int)T->slabs.size();
+    auto send_lo = [&](nf_solver *S) { return which == 0 ? S->d_clo : S->d_hlo + (size_t)g * S->nlines[2]; };
+    auto send_hi = [&](nf_solver *S) { return which == 0 ? S->d_chi : S->d_hhi + (size_t)g * S->nlines[2]; };
+    for (int i = 0; i + 1 < ns; ++i) {                            // interfaces between local slabs
+        nf_solver *A = T->slabs[i], *B = T->slabs[i + 1];
+        const size_t bytes = (size_t)A->nlines[2] * sizeof(double);
+        HIPCHK(hipMemcpyAsync(B->d_rlo, send_hi(A), bytes, hipMemcpyDeviceToDevice, T->stream));
+        HIPCHK(hipMemcpyAsync(A->d_rhi, send_lo(B), bytes, hipMemcpyDeviceToDevice, T->stream));
+    }
+    nf_solver *bot = T->slabs.front(), *top = T->slabs.back();
+    if (T->nproc > 1 && (bot->if_lo || top->if_hi)) {
+        const size_t cnt = (size_t)bot->nlines[2];
+        NCCLCHK(g_rccl.GroupStart());
+        if (bot->if_lo) {
+            NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, T->stream));
+            NCCLCHK(g_rccl.Recv(bot->d_rlo, cnt, NCCL_DOUBLE, T->rank - 1, T->comm, T->stream));
+        }
+        if (top->if_hi) {
+            NCCLCHK(g_rccl.Send(send_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, T->stream));
+            NCCLCHK(g_rccl.Recv(top->d_rhi, cnt, NCCL_DOUBLE, T->rank + 1, T->comm, T->stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    } else if (bot->if_lo || top->if_hi) {
+        return fail(NF_ERR_STATE, "slab %s has an interface but no neighbour: link the slabs (nf_link_slabs) or init the communicator (nf_comm_init)",
+                    bot->if_lo ? "bottom" : "top");
+    }
+    return NF_OK;
+}
+
+// build-time: S_red = own half + neighbour's half for every separator; checks that separators decouple
+static int team_prepare(nf_team *T)
+{
+    if (T->linked_ready) return NF_OK;
+    bool any = false;
+    for (auto *S : T->slabs) { if (!S->built) return fail(NF_ERR_STATE, "every slab must be built (nf_build) before solving"); any |= S->if_lo || S->if_hi; }
+    if (any) {
+        const int ng = T->slabs[0]->ng;
+        for (int g = 0; g < ng; ++g) {
+            NFCHK(exchange_planes(T, 1, g));
+            for (auto *S : T->slabs) {
+                const long nl = S->nlines[2];
+                const unsigned gr = (unsigned)((nl + 255) / 256);
+                if (S->if_lo) hipLaunchKernelGGL(k_sred_inv, dim3(gr), dim3(256), 0, T->stream, S->d_hlo + g * nl, S->d_rlo, S->d_sinv_lo + g * nl, nl, 0);
+                if (S->if_hi) hipLaunchKernelGGL(k_sred_inv, dim3(gr), dim3(256), 0, T->stream, S->d_hhi + g * nl, S->d_rhi, S->d_sinv_hi + g * nl, nl, 1);
+            }
+            HIPCHK(hipStreamSynchronize(T->stream));
+        }
+        // separators must decouple through a slab: |a_lo a_hi (T_II^-1)[first,last]| * sqrt(sinv_lo sinv_hi) <= 1e-15
+        for (auto *S : T->slabs) {
+            if (!(S->if_lo && S->if_hi)) continue;
+            const size_t nl = (size_t)S->nlines[2] * ng;
+            std::vector<double> gfl(nl), slo(nl), shi(nl);
+            HIPCHK(hipMemcpy(gfl.data(), S->d_gfl, nl * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(slo.data(), S->d_sinv_lo, nl * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(shi.data(), S->d_sinv_hi, nl * sizeof(double), hipMemcpyDeviceToHost));
+            double worst = 0.0;
+            for (size_t i = 0; i < nl; ++i) worst = std::max(worst, std::fabs(gfl[i]) * std::sqrt(std::fabs(slo[i] * shi[i])));
+            if (worst > 1e-15)
+                return fail(NF_ERR_UNSUPPORTED, "slab of %d z-planes is too thin: separator coupling %.2e > 1e-15 (use slabs of >= ~30 planes)", S->nz, worst);
+        }
+    }
+    T->linked_ready = true;
+    return NF_OK;
+}
+
+// process-local sum of the partials (+ all-reduce over ranks) + the scalar logic of `op`
+static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int nq, double *out, double tol, int maxit)
+{
+    PartSegs ps = segs_for(T, counts);
+    if (!T->rccl_reduce) {
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 0, T->d_red);
+    } else {
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 1, T->d_red);
+        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
+        hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, T->stream, op, T->d_red, nq, T->d_cg, out, tol, maxit);
+    }
+    return NF_OK;
 }
 
 // ---- Schur apply -----------------------------------------------------------------------------
@@ -299,11 +566,12 @@ static void launch_x_t(nf_solver *S, int g, const double *x, double *y, int lpl_
 {
     const long N = S->N; const double beta = (double)(1 << (S->dim - 1));
     const bool vec = (S->nx % 2 == 0);
+    hipStream_t st = S->team->stream;
     if (vec)
-        hipLaunchKernelGGL((k_schur_x<K, NCH, true>), dim3(grid), dim3(256), 0, S->stream, x, y, S->d_L[0] + g * N, S->d_DR[0] + g * N,
+        hipLaunchKernelGGL((k_schur_x<K, NCH, true>), dim3(grid), dim3(256), 0, st, x, y, S->d_L[0] + g * N, S->d_DR[0] + g * N,
                            S->d_D0[0] + g * S->nlines[0], S->d_Cd + g * N, S->nx, S->nlines[0], lpl_log2, beta, first, last, partials, cg);
     else
-        hipLaunchKernelGGL((k_schur_x<K, NCH, false>), dim3(grid), dim3(256), 0, S->stream, x, y, S->d_L[0] + g * N, S->d_DR[0] + g * N,
+        hipLaunchKernelGGL((k_schur_x<K, NCH, false>), dim3(grid), dim3(256), 0, st, x, y, S->d_L[0] + g * N, S->d_DR[0] + g * N,
                            S->d_D0[0] + g * S->nlines[0], S->d_Cd + g * N, S->nx, S->nlines[0], lpl_log2, beta, first, last, partials, cg);
 }
 
@@ -324,102 +592,169 @@ static int launch_x(nf_solver *S, int g, const double *x, double *y, int last, d
     return NF_OK;
 }
 
-static int launch_s(nf_solver *S, int d, int g, const double *x, double *y, int last, double *partials, const CgScalars *cg, int *nparts)
+// zmode: 0 = plain line kernel (y lines, or z lines of an undivided mesh); 1 / 2 = slab chain passes (z lines)
+static int launch_s(nf_solver *S, int d, int g, const double *x, double *y, int last, double *partials, const CgScalars *cg, int *nparts, int zmode)
 {
+    nf_team *T = S->team;
     const long N = S->N; const double beta = (double)(1 << (S->dim - 1));
     const int n = d == 1 ? S->ny : S->nz;
     const long nxy = (long)S->nx * S->ny;
     const long sl = d == 1 ? S->nx : nxy, ostride = d == 1 ? nxy : S->nx;
     const int nouter = d == 1 ? S->nz : S->ny;
-    const bool pair = S->opt_s_pair && (S->nx % 2 == 0);          // two columns per thread, double2 accesses
-    int SEG = S->opt_s_seg ? S->opt_s_seg : (pair ? (n <= 256 ? 4 : 8) : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
+    const bool pair = zmode == 0 && T->opt_s_pair && (S->nx % 2 == 0);   // two columns per thread, double2 accesses
+    int SEG = T->opt_s_seg ? T->opt_s_seg : (pair ? (n <= 256 ? 4 : 8) : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
     int NSEG = (n + SEG - 1) / SEG;
     if (NSEG > 128) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit", n);
     const int cols = pair ? (S->nx + 1) / 2 : S->nx;              // thread columns needed
-    int TX = S->opt_s_tx ? S->opt_s_tx : 64;
+    int TX = T->opt_s_tx ? T->opt_s_tx : 64;
     while (TX > 8 && TX * NSEG > 1024) TX >>= 1;
     if (TX * NSEG > 1024) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than 1024 threads per block", n);
     while (TX > 8 && TX / 2 >= cols) TX >>= 1;                    // narrow meshes
     dim3 grid((unsigned)((cols + TX - 1) / TX), (unsigned)nouter), block((unsigned)(TX * NSEG));
     if (nparts) *nparts = (int)(grid.x * grid.y);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
+    hipStream_t st = T->stream;
+    SlabArgs sa; memset(&sa, 0, sizeof sa);
     if (pair) {
         const size_t lds = (size_t)(4 * TX * NSEG + TX) * sizeof(double2) + 16 * sizeof(double);
-#define NF_LAUNCH_S2(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s2<SEGV, DIRV>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
+#define NF_LAUNCH_S2(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s2<SEGV, DIRV>), grid, block, lds, st, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
         if (d == 1) { if (SEG == 4) NF_LAUNCH_S2(4, 1); else if (SEG == 8) NF_LAUNCH_S2(8, 1); else if (SEG == 16) NF_LAUNCH_S2(16, 1); else return fail(NF_ERR_ARG, "bad s_seg"); }
         else        { if (SEG == 4) NF_LAUNCH_S2(4, 2); else if (SEG == 8) NF_LAUNCH_S2(8, 2); else if (SEG == 16) NF_LAUNCH_S2(16, 2); else return fail(NF_ERR_ARG, "bad s_seg"); }
 #undef NF_LAUNCH_S2
-    } else {
-        const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
-#define NF_LAUNCH_S(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV>), grid, block, lds, S->stream, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
+        return NF_OK;
+    }
+    const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
+    if (zmode == 0) {
+#define NF_LAUNCH_S(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, false>), grid, block, lds, st, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg, sa)
         if (d == 1) { if (SEG == 4) NF_LAUNCH_S(4, 1); else if (SEG == 8) NF_LAUNCH_S(8, 1); else if (SEG == 16) NF_LAUNCH_S(16, 1); else if (SEG == 32) NF_LAUNCH_S(32, 1); else return fail(NF_ERR_ARG, "bad s_seg"); }
         else        { if (SEG == 4) NF_LAUNCH_S(4, 2); else if (SEG == 8) NF_LAUNCH_S(8, 2); else if (SEG == 16) NF_LAUNCH_S(16, 2); else if (SEG == 32) NF_LAUNCH_S(32, 2); else return fail(NF_ERR_ARG, "bad s_seg"); }
 #undef NF_LAUNCH_S
+        return NF_OK;
     }
+    const long nl = S->nlines[2];
+    sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
+    sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
+#define NF_LAUNCH_SS(SEGV) hipLaunchKernelGGL((k_schur_s<SEGV, 2, true>), grid, block, lds, st, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg, sa)
+    if (SEG == 4) NF_LAUNCH_SS(4); else if (SEG == 8) NF_LAUNCH_SS(8); else if (SEG == 16) NF_LAUNCH_SS(16); else if (SEG == 32) NF_LAUNCH_SS(32); else return fail(NF_ERR_ARG, "bad s_seg");
+#undef NF_LAUNCH_SS
     return NF_OK;
 }
 
-// y = S_g x ; if partials != NULL the last pass leaves *nparts block partials of x.y there
-static int schur_apply(nf_solver *S, int g, const double *x, double *y, double *partials, const CgScalars *cg, int *nparts)
+// y = S_g x on every local slab.  xs / ys: per-slab device pointers.  With `want_dot` the last pass leaves the block
+// partials of x.y in the team buffer and counts[] receives the number per slab.
+static int team_schur_apply(nf_team *T, int g, const std::vector<const double *> &xs, const std::vector<double *> &ys, bool want_dot,
+                            const CgScalars *cg, std::vector<int> *counts)
 {
+    const int ns = (int)T->slabs.size();
+    const int dim = T->slabs[0]->dim;
+    bool any_if = false; for (auto *S : T->slabs) any_if |= S->if_lo || S->if_hi;
     hipEvent_t a, b, ta = nullptr, tb = nullptr;
-    if (S->profile) prof_begin(S, 3, &ta, &tb);
-    for (int d = 0; d < S->dim; ++d) {
-        const int last = d == S->dim - 1;
-        if (S->profile) prof_begin(S, d, &a, &b);
-        if (d == 0) NFCHK(launch_x(S, g, x, y, last, partials, cg, last ? nparts : nullptr));
-        else NFCHK(launch_s(S, d, g, x, y, last, partials, cg, last ? nparts : nullptr));
-        if (S->profile) (void)hipEventRecord(b, S->stream);
+    if (T->profile) prof_begin(T, 3, &ta, &tb);
+    if (any_if) {                                                 // partition method step 1 + interface exchange
+        if (T->profile) prof_begin(T, 4, &a, &b);
+        for (int i = 0; i < ns; ++i) { nf_solver *S = T->slabs[i]; if (S->if_lo || S->if_hi) NFCHK(launch_s(S, 2, g, xs[i], ys[i], 0, nullptr, cg, nullptr, 1)); }
+        if (T->profile) (void)hipEventRecord(b, T->stream);
+        NFCHK(exchange_planes(T, 0, 0));
     }
-    if (S->profile) (void)hipEventRecord(tb, S->stream);
+    for (int d = 0; d < dim; ++d) {
+        const int last = d == dim - 1;
+        if (T->profile) prof_begin(T, d, &a, &b);
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            double *part = (want_dot && last) ? T->d_partials + i * T->slab_cap : nullptr;
+            int np = 0;
+            if (d == 0) NFCHK(launch_x(S, g, xs[i], ys[i], last, part, cg, &np));
+            else if (d == 2 && (S->if_lo || S->if_hi)) {
+                const long nl = S->nlines[2];
+                hipLaunchKernelGGL(k_separators, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, T->stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi,
+                                   S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg);
+                NFCHK(launch_s(S, 2, g, xs[i], ys[i], last, part, cg, &np, 2));
+            } else NFCHK(launch_s(S, d, g, xs[i], ys[i], last, part, cg, &np, 0));
+            if (counts && last) (*counts)[i] = np;
+        }
+        if (T->profile) (void)hipEventRecord(b, T->stream);
+    }
+    if (T->profile) (void)hipEventRecord(tb, T->stream);
     return NF_OK;
 }
+
+static bool team_is_single(const nf_team *T) { return T->slabs.size() == 1 && !T->slabs[0]->if_lo && !T->slabs[0]->if_hi; }
 
 int nf_schur_apply(nf_handle S, int g, const double *x_dev, double *y_dev)
 {
     if (!S || !x_dev || !y_dev || g < 0 || g >= S->ng) return fail(NF_ERR_ARG, "nf_schur_apply: bad arguments");
     if (!S->built) return fail(NF_ERR_STATE, "nf_schur_apply: call nf_build first");
+    nf_team *T = S->team;
+    if (!team_is_single(T)) return fail(NF_ERR_STATE, "nf_schur_apply works on an undivided mesh; use nf_team_schur_apply for slabs");
     HIPCHK(hipSetDevice(S->device));
-    NFCHK(schur_apply(S, g, x_dev, y_dev, nullptr, nullptr, nullptr));
+    NFCHK(team_schur_apply(T, g, { x_dev }, { y_dev }, false, nullptr, nullptr));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(S->stream));
-    if (S->profile) prof_collect(S);
+    HIPCHK(hipStreamSynchronize(T->stream));
+    if (T->profile) prof_collect(T);
+    return NF_OK;
+}
+
+// team variant: x/y pointer arrays with one entry per local slab (N_slab doubles each, device)
+int nf_team_schur_apply(nf_handle S, int g, const double *const *x_dev, double *const *y_dev)
+{
+    if (!S || !x_dev || !y_dev || g < 0 || g >= S->ng) return fail(NF_ERR_ARG, "nf_team_schur_apply: bad arguments");
+    nf_team *T = S->team;
+    HIPCHK(hipSetDevice(T->device));
+    NFCHK(team_prepare(T));
+    std::vector<const double *> xs(x_dev, x_dev + T->slabs.size()); std::vector<double *> ys(y_dev, y_dev + T->slabs.size());
+    NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(T->stream));
+    if (T->profile) prof_collect(T);
     return NF_OK;
 }
 
 // ---- CG (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636) -----------------------------
-static int cg_solve(nf_solver *S, int g, const double *rhs, double *x, double tol, int maxit, int *its_out, double *res_out)
+// rhs / x: per-slab pointers
+static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, const std::vector<double *> &x, double tol, int maxit,
+                    int *its_out, double *res_out)
 {
-    const long N = S->N; const int G = grid_for(N);
-    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(256), 0, S->stream, rhs, x, S->d_r, S->d_p, N, S->d_partials);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, S->stream, (int)FIN_RHS, S->d_partials, G, S->partial_stride, 1, S->d_cg, S->d_out, tol, maxit);
+    const int ns = (int)T->slabs.size();
+    std::vector<int> gcnt(ns), acnt(ns);
+    std::vector<const double *> ps(ns); std::vector<double *> qs(ns);
+    for (int i = 0; i < ns; ++i) {
+        nf_solver *S = T->slabs[i];
+        gcnt[i] = grid_for(S->N); ps[i] = S->d_p; qs[i] = S->d_q;
+        hipLaunchKernelGGL(k_cg_init, dim3(gcnt[i]), dim3(256), 0, T->stream, rhs[i], x[i], S->d_r, S->d_p, S->N, T->d_partials + i * T->slab_cap);
+    }
+    NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
     CgScalars sc; memset(&sc, 0, sizeof sc);
     int launched = 0;
-    int batch = S->cg_batch > 0 ? S->cg_batch : std::max(1, S->last_its[g] - 1);
+    int batch = T->cg_batch > 0 ? T->cg_batch : std::max(1, T->last_its[g] - 1);
     while (launched < maxit) {
         int nb = std::min(batch, maxit - launched);
-        for (int i = 0; i < nb; ++i) {
-            int nparts = 0;
-            NFCHK(schur_apply(S, g, S->d_p, S->d_q, S->d_partials, S->d_cg, &nparts));
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, S->stream, (int)FIN_PAP, S->d_partials, nparts, S->partial_stride, 1, S->d_cg, S->d_out, 0.0, 0);
-            hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(256), 0, S->stream, x, S->d_r, S->d_p, S->d_q, N, S->d_cg, S->d_partials);
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, S->stream, (int)FIN_RR, S->d_partials, G, S->partial_stride, 1, S->d_cg, S->d_out, 0.0, 0);
-            hipLaunchKernelGGL(k_cg_pupdate, dim3(G), dim3(256), 0, S->stream, S->d_p, S->d_r, N, S->d_cg);
+        for (int it = 0; it < nb; ++it) {
+            NFCHK(team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt));
+            NFCHK(team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0));
+            for (int i = 0; i < ns; ++i) {
+                nf_solver *S = T->slabs[i];
+                hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->N, T->d_cg, T->d_partials + i * T->slab_cap);
+            }
+            NFCHK(team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0));
+            for (int i = 0; i < ns; ++i) {
+                nf_solver *S = T->slabs[i];
+                hipLaunchKernelGGL(k_cg_pupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_p, S->d_r, S->N, T->d_cg);
+            }
         }
         launched += nb;
-        HIPCHK(hipMemcpyAsync(&sc, S->d_cg, sizeof sc, hipMemcpyDeviceToHost, S->stream));
-        HIPCHK(hipStreamSynchronize(S->stream));
+        HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
+        HIPCHK(hipStreamSynchronize(T->stream));
         if (sc.done) break;
-        batch = S->cg_batch > 0 ? S->cg_batch : (launched < 8 ? 1 : 2);
+        batch = T->cg_batch > 0 ? T->cg_batch : (launched < 8 ? 1 : 2);
     }
     if (launched == 0) {
-        HIPCHK(hipMemcpyAsync(&sc, S->d_cg, sizeof sc, hipMemcpyDeviceToHost, S->stream));
-        HIPCHK(hipStreamSynchronize(S->stream));
+        HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
+        HIPCHK(hipStreamSynchronize(T->stream));
     }
     HIPCHK(hipGetLastError());
-    if (S->profile) prof_collect(S);
+    if (T->profile) prof_collect(T);
     if (!std::isfinite(sc.rr)) return fail(NF_ERR_NUMERIC, "CG produced a non-finite residual (group %d)", g);
-    S->last_its[g] = sc.its;
+    T->last_its[g] = sc.its;
     if (its_out) *its_out = sc.its;
     if (res_out) *res_out = sc.rhs_norm > 0 ? std::sqrt(sc.rr) / sc.rhs_norm : 0.0;
     return NF_OK;
@@ -429,8 +764,9 @@ int nf_solve_group(nf_handle S, int g, const double *rhs_dev, double *phi_dev, d
 {
     if (!S || !rhs_dev || !phi_dev || g < 0 || g >= S->ng) return fail(NF_ERR_ARG, "nf_solve_group: bad arguments");
     if (!S->built) return fail(NF_ERR_STATE, "nf_solve_group: call nf_build first");
+    if (!team_is_single(S->team)) return fail(NF_ERR_STATE, "nf_solve_group works on an undivided mesh");
     HIPCHK(hipSetDevice(S->device));
-    return cg_solve(S, g, rhs_dev, phi_dev, tol, maxit, its, res);
+    return cg_solve(S->team, g, { rhs_dev }, { phi_dev }, tol, maxit, its, res);
 }
 
 // ---- diagonal cache ----------------------------------------------------------------------------
@@ -438,15 +774,16 @@ int nf_build_diagonal_cache(nf_handle S)
 {
     if (!S) return fail(NF_ERR_ARG, "null handle");
     if (!S->built) return fail(NF_ERR_STATE, "nf_build_diagonal_cache: call nf_build first");
+    if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh");
     if (S->diag_valid) return NF_OK;
     HIPCHK(hipSetDevice(S->device));
     const long N = S->N;
     NFCHK(dalloc(&S->d_Sinv, (size_t)N * S->ng));
     Geom G = make_geom(S);
     for (int g = 0; g < S->ng; ++g)
-        hipLaunchKernelGGL(k_diag_cache, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, S->stream, G, S->d_D + g * N, S->d_Cd + g * N, S->d_Sinv + g * N, N);
+        hipLaunchKernelGGL(k_diag_cache, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, S->team->stream, G, S->d_D + g * N, S->d_Cd + g * N, S->d_Sinv + g * N, N);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipStreamSynchronize(S->team->stream));
     S->diag_valid = true;
     return NF_OK;
 }
@@ -463,6 +800,7 @@ int nf_set_phi(nf_handle S, const double *phi)
 {
     if (!S || !phi) return fail(NF_ERR_ARG, "nf_set_phi: bad arguments");
     HIPCHK(hipSetDevice(S->device));
+    HIPCHK(hipStreamSynchronize(S->team->stream));
     HIPCHK(hipMemcpy(S->d_phi, phi, (size_t)S->N * S->ng * sizeof(double), hipMemcpyHostToDevice));
     return NF_OK;
 }
@@ -470,7 +808,7 @@ int nf_get_phi(nf_handle S, double *phi)
 {
     if (!S || !phi) return fail(NF_ERR_ARG, "nf_get_phi: bad arguments");
     HIPCHK(hipSetDevice(S->device));
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipStreamSynchronize(S->team->stream));
     HIPCHK(hipMemcpy(phi, S->d_phi, (size_t)S->N * S->ng * sizeof(double), hipMemcpyDeviceToHost));
     return NF_OK;
 }
@@ -480,16 +818,18 @@ int nf_reset_flux(nf_handle S)
     HIPCHK(hipSetDevice(S->device));
     std::vector<double> ones((size_t)S->N * S->ng, 1.0);        // Sol_Phi_ = 1, src/NeutFEM.cpp:347-354
     HIPCHK(hipMemcpy(S->d_phi, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
-    S->has_valid_keff = 0; S->raw_valid = false;
+    S->team->has_valid_keff = 0; S->raw_valid = false;
     return NF_OK;
 }
-int nf_set_warm_state(nf_handle S, int v, double k) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->has_valid_keff = v; S->last_keff = k; return NF_OK; }
-int nf_get_warm_state(nf_handle S, int *v, double *k) { if (!S) return fail(NF_ERR_ARG, "null handle"); if (v) *v = S->has_valid_keff; if (k) *k = S->last_keff; return NF_OK; }
+int nf_set_warm_state(nf_handle S, int v, double k) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->team->has_valid_keff = v; S->team->last_keff = k; return NF_OK; }
+int nf_get_warm_state(nf_handle S, int *v, double *k) { if (!S) return fail(NF_ERR_ARG, "null handle"); if (v) *v = S->team->has_valid_keff; if (k) *k = S->team->last_keff; return NF_OK; }
 
 int nf_get_J(nf_handle S, double *J_host)
 {
     if (!S || !J_host) return fail(NF_ERR_ARG, "nf_get_J: bad arguments");
+    if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "nf_get_J is not available on a slab (currents are reconstructed on undivided meshes only)");
     HIPCHK(hipSetDevice(S->device));
+    hipStream_t st = S->team->stream;
     const long N = S->N, nJ = S->nJ;
     if (!S->raw_valid) { memset(J_host, 0, sizeof(double) * nJ * S->ng); return NF_OK; }   // Sol_J_ = 0 before any solve
     double *dJ = nullptr; NFCHK(dalloc(&dJ, (size_t)nJ));
@@ -497,11 +837,11 @@ int nf_get_J(nf_handle S, double *J_host)
     const long off[3] = { 0, S->nJx, S->nJx + S->nJy };
     for (int g = 0; g < S->ng; ++g) {
         for (int d = 0; d < S->dim; ++d)
-            hipLaunchKernelGGL(k_flux_to_J, dim3((unsigned)((S->nlines[d] + 63) / 64)), dim3(64), 0, S->stream, G, d, S->d_D + g * N,
+            hipLaunchKernelGGL(k_flux_to_J, dim3((unsigned)((S->nlines[d] + 63) / 64)), dim3(64), 0, st, G, d, S->d_D + g * N,
                                S->d_raw + g * N, S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * S->nlines[d], dJ + off[d],
                                S->nlines[d], S->raw_is_diag ? 1 : 0);
-        HIPCHK(hipMemcpyAsync(J_host + (size_t)g * nJ, dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, S->stream));
-        HIPCHK(hipStreamSynchronize(S->stream));
+        HIPCHK(hipMemcpyAsync(J_host + (size_t)g * nJ, dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
     }
     dfree(dJ);
     HIPCHK(hipGetLastError());
@@ -509,12 +849,13 @@ int nf_get_J(nf_handle S, double *J_host)
 }
 
 // ---- SolveCoarse (src/NeutFEM.cpp:2380-2611) ---------------------------------------------------
-static int solve_keff_impl(nf_solver *S, const nf_keff_opts *o, double *keff, int *n_outer);
+static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff, int *n_outer);
 
 // builds + solves the coarse problem on the device; the prolonged flux is written to d_dst (ng*N)
 static int coarse_init(nf_solver *S, const nf_keff_opts *o, double *k_coarse, double *d_dst, bool *done)
 {
     *done = false;
+    nf_team *T = S->team;
     const int dim = S->dim, ng = S->ng;
     const int nf = o->n_coarse_factors;
     int rx = nf > 0 ? std::max(o->coarse_factors[0], 1) : 1;
@@ -529,34 +870,33 @@ static int coarse_init(nf_solver *S, const nf_keff_opts *o, double *k_coarse, do
     nf_handle C = nullptr;
     NFCHK(nf_create(0, 0, ng, nxc + 1, xc.data(), (int)yc.size(), yc.data(), (int)zc.size(), zc.data(), S->device, &C));
     for (int a = 0; a < 8; ++a) if (S->bc_set[a]) nf_set_bc(C, a, S->bc_type[a]);
-    const long Nc = C->N; const size_t NNc = (size_t)Nc * ng;
+    const long Nc = C->N;
     int rc = NF_OK;
     auto coarsen = [&](const double *fine, double **coarse, int nfields) -> int {
         NFCHK(dalloc(coarse, (size_t)Nc * nfields));
-        hipLaunchKernelGGL(k_coarsen, dim3((unsigned)((Nc + 127) / 128)), dim3(128), 0, S->stream, fine, *coarse, S->d_xb, S->d_yb, S->d_zb,
+        hipLaunchKernelGGL(k_coarsen, dim3((unsigned)((Nc + 127) / 128)), dim3(128), 0, T->stream, fine, *coarse, S->d_xb, S->d_yb, S->d_zb,
                            dim, S->nx, S->ny, S->nz, rx, ry, rz, nfields);
         return NF_OK;
     };
-    (void)NNc;
     rc = coarsen(S->d_D, &C->d_D, ng);
     if (rc == NF_OK) rc = coarsen(S->d_SigR, &C->d_SigR, ng);
     if (rc == NF_OK) rc = coarsen(S->d_NSF, &C->d_NSF, ng);
     if (rc == NF_OK) rc = coarsen(S->d_Chi, &C->d_Chi, ng);
     for (int i = 0; i < ng * ng && rc == NF_OK; ++i)
         if (S->d_SigS[i]) rc = coarsen(S->d_SigS[i], &C->d_SigS[i], 1);    // mean of an all-zero block is zero
-    if (rc == NF_OK && hipStreamSynchronize(S->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "coarsen failed");
+    if (rc == NF_OK && hipStreamSynchronize(T->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "coarsen failed");
     if (rc == NF_OK) { C->xs_uploaded = true; rc = nf_build(C); }
     double kc = 1.0; int nout = 0;
     if (rc == NF_OK) {
         nf_keff_opts co = *o;                                    // :2460-2467
         co.tol_keff = o->tol_keff * 10.0; co.tol_flux = o->tol_flux * 10.0; co.max_outer = o->max_outer / 2;
         co.use_coarse_init = 0; co.n_coarse_factors = 0; co.use_diagonal_solver = 0; co.solver_type_pushed = 1; co.profile = 0;
-        rc = solve_keff_impl(C, &co, &kc, &nout);
+        rc = solve_keff_impl(C->team, &co, &kc, &nout);
     }
     if (rc == NF_OK) {
-        S->coarse_outer = nout;
-        hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, C->stream, C->d_phi, d_dst, S->nx, S->ny, S->nz, rx, ry, rz, ng);
-        if (hipStreamSynchronize(C->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
+        T->coarse_outer = nout;
+        hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, C->team->stream, C->d_phi, d_dst, S->nx, S->ny, S->nz, rx, ry, rz, ng);
+        if (hipStreamSynchronize(C->team->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
     }
     std::string keep = g_err;
     nf_destroy(C);
@@ -569,6 +909,7 @@ int nf_solve_coarse(nf_handle S, const nf_keff_opts *o, double *k_coarse, double
 {
     if (!S || !o || !k_coarse || !phi_host) return fail(NF_ERR_ARG, "nf_solve_coarse: bad arguments");
     if (!S->built) return fail(NF_ERR_STATE, "nf_solve_coarse: call nf_build first");
+    if (!team_is_single(S->team)) return fail(NF_ERR_UNSUPPORTED, "coarse-mesh initialisation is not available on a slab-decomposed mesh");
     HIPCHK(hipSetDevice(S->device));
     const size_t NN = (size_t)S->N * S->ng;
     bool done = false; double kc = 1.0;
@@ -580,21 +921,26 @@ int nf_solve_coarse(nf_handle S, const nf_keff_opts *o, double *k_coarse, double
 }
 
 // ---- SolveKeff (src/NeutFEM.cpp:1627-1815) -----------------------------------------------------
-static int solve_keff_impl(nf_solver *S, const nf_keff_opts *o, double *keff_out, int *n_outer)
+static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, int *n_outer)
 {
-    const int ng = S->ng; const long N = S->N; const long NT = N * ng;
-    const int G = grid_for(N), GT = grid_for(NT);
+    const int ns = (int)T->slabs.size();
+    nf_solver *S0 = T->slabs[0];
+    const int ng = S0->ng;
+    const bool single = team_is_single(T);
+    NFCHK(team_prepare(T));
     int use_diag = o->use_diagonal_solver ? 1 : 0;                // RT0-P0 only exists here
-    if (use_diag) NFCHK(nf_build_diagonal_cache(S));
-    double keff = S->has_valid_keff ? S->last_keff : 1.0;        // :1662
-    S->coarse_outer = 0;
+    if (use_diag) { if (!single) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh"); NFCHK(nf_build_diagonal_cache(S0)); }
+    double keff = T->has_valid_keff ? T->last_keff : 1.0;        // :1662
+    T->coarse_outer = 0;
     if (o->use_coarse_init && o->n_coarse_factors > 0) {          // :1665-1670
+        if (!single) return fail(NF_ERR_UNSUPPORTED, "coarse-mesh initialisation is not available on a slab-decomposed mesh");
         bool done = false; double kc = 1.0;
-        NFCHK(coarse_init(S, o, &kc, S->d_phi, &done));
+        NFCHK(coarse_init(S0, o, &kc, S0->d_phi, &done));
         keff = done ? kc : 1.0;
     }
+    long Ntot = 0; for (auto *S : T->slabs) Ntot += S->N;
     // SchurSolver type: DIRECT_* or n_phi < 200 -> "exact" solve (CG to 1e-14 stands in)
-    const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || N < 200;
+    const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (single && Ntot < 200);
     const double cg_tol = direct ? 1e-14 : o->tol_flux;           // SetTolerance forwards tol_flux (:334)
     const int cg_max = direct ? 100000 : o->max_inner;
     // ChebyshevAccel(15, 0.98), src/solvers.cpp:664-700
@@ -603,29 +949,42 @@ static int solve_keff_impl(nf_solver *S, const nf_keff_opts *o, double *keff_out
     { const double Gm = std::acosh(2. / sigma - 1.); ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
       for (int i = 2; i < nmax; ++i) { ca[i] = std::cosh((i - 1) * Gm) / std::cosh(i * Gm); cbv[i] = std::cosh((i - 2) * Gm) / std::cosh(i * Gm); } }
     int cheb_it = 0;
-    S->hist_k.clear(); S->hist_dk.clear(); S->hist_dphi.clear(); S->hist_cg.clear();
-    S->last_outer = 0; S->last_cg_total = 0;
-    S->profile = o->profile != 0;
+    T->hist_k.clear(); T->hist_dk.clear(); T->hist_dphi.clear(); T->hist_cg.clear();
+    T->last_outer = 0; T->last_cg_total = 0;
+    T->profile = o->profile != 0;
     ScatterArgs sa; sa.ng = ng;
     double hout[4];
+    std::vector<int> gN(ns), gT(ns);
+    std::vector<const double *> rhs(ns); std::vector<double *> sol(ns);
+    for (int i = 0; i < ns; ++i) { gN[i] = grid_for(T->slabs[i]->N); gT[i] = grid_for(T->slabs[i]->N * ng); }
     for (int it = 0; it < o->max_outer; ++it) {
         // total_fiss and prod_old (:1700-1707)
-        hipLaunchKernelGGL(k_fission, dim3(G), dim3(256), 0, S->stream, S->d_Mf, S->d_phi, ng, N, S->d_tf, S->d_partials);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, S->stream, (int)FIN_SUM, S->d_partials, G, S->partial_stride, 1, S->d_cg, S->d_out, 0.0, 0);
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_phi, ng, S->N, S->d_tf, T->d_partials + i * T->slab_cap);
+        }
+        NFCHK(team_finalize(T, FIN_SUM, gN, 1, T->d_out, 0.0, 0));
         for (int g = 0; g < ng; ++g) {
-            for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[g * ng + gp] : nullptr;
-            double *dst = use_diag ? S->d_raw + g * N : S->d_rhs;
-            hipLaunchKernelGGL(k_group_rhs, dim3(G), dim3(256), 0, S->stream, sa, g, S->d_Chi + g * N, S->d_tf, 1.0 / keff, S->d_raw, S->d_phi,
-                               use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, N);
+            for (int i = 0; i < ns; ++i) {
+                nf_solver *S = T->slabs[i]; const long N = S->N;
+                for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[g * ng + gp] : nullptr;
+                double *dst = use_diag ? S->d_raw + g * N : S->d_rhs;
+                hipLaunchKernelGGL(k_group_rhs, dim3(gN[i]), dim3(256), 0, T->stream, sa, g, S->d_Chi + g * N, S->d_tf, 1.0 / keff, S->d_raw, S->d_phi,
+                                   use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, N);
+                rhs[i] = S->d_rhs; sol[i] = S->d_raw + g * N;
+            }
             int its = 0;
-            if (!use_diag) NFCHK(cg_solve(S, g, S->d_rhs, S->d_raw + g * N, cg_tol, cg_max, &its, nullptr));
-            S->hist_cg.push_back(its); S->last_cg_total += its;
+            if (!use_diag) NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr));
+            T->hist_cg.push_back(its); T->last_cg_total += its;
         }
         // prod_new, norms (:1766-1779)
-        hipLaunchKernelGGL(k_outer_reduce, dim3(GT), dim3(256), 0, S->stream, S->d_Mf, S->d_raw, S->d_phi, NT, S->d_partials, S->partial_stride);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, S->stream, (int)FIN_SUM, S->d_partials, GT, S->partial_stride, 3, S->d_cg, S->d_out + 1, 0.0, 0);
-        HIPCHK(hipMemcpyAsync(hout, S->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
-        HIPCHK(hipStreamSynchronize(S->stream));
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            hipLaunchKernelGGL(k_outer_reduce, dim3(gT[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_raw, S->d_phi, S->N * ng, T->d_partials + i * T->slab_cap, T->partial_stride);
+        }
+        NFCHK(team_finalize(T, FIN_SUM, gT, 3, T->d_out + 1, 0.0, 0));
+        HIPCHK(hipMemcpyAsync(hout, T->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, T->stream));
+        HIPCHK(hipStreamSynchronize(T->stream));
         const double prod_old = hout[0], prod_new = hout[1], nsq = hout[2], dsq = hout[3];
         const double keff_new = keff * (prod_new / prod_old);
         const double dk = std::fabs(keff_new - keff);
@@ -640,44 +999,48 @@ static int solve_keff_impl(nf_solver *S, const nf_keff_opts *o, double *keff_out
             if (cheb_it == 0) { mode = 1; }
             else if (cheb_it == 1) { mode = 2; a = ca[1]; }
             else { mode = 3; a = (4. / sigma) * ca[cheb_it]; b = cbv[cheb_it]; }
-            if (!S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NT)); NFCHK(dalloc(&S->d_p1, (size_t)NT)); }
         }
-        hipLaunchKernelGGL(k_normalize_cheb, dim3(GT), dim3(256), 0, S->stream, S->d_raw, S->d_phi, S->d_p0, S->d_p1, NT, norm,
-                           norm > 1e-14 ? 1 : 0, mode, a, b);
-        if (mode == 3) std::swap(S->d_p0, S->d_p1);
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i]; const long NT = S->N * ng;
+            if (mode && !S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NT)); NFCHK(dalloc(&S->d_p1, (size_t)NT)); }
+            hipLaunchKernelGGL(k_normalize_cheb, dim3(gT[i]), dim3(256), 0, T->stream, S->d_raw, S->d_phi, S->d_p0, S->d_p1, NT, norm,
+                               norm > 1e-14 ? 1 : 0, mode, a, b);
+            if (mode == 3) std::swap(S->d_p0, S->d_p1);
+        }
         if (it >= 2) ++cheb_it;
-        S->hist_k.push_back(keff); S->hist_dk.push_back(dk); S->hist_dphi.push_back(dphi);
-        S->last_outer = it + 1;
+        T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
+        T->last_outer = it + 1;
         if (dk < o->tol_keff && dphi < o->tol_flux) break;        // :1799-1802
     }
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipStreamSynchronize(T->stream));
     HIPCHK(hipGetLastError());
-    if (S->profile) prof_collect(S);
-    S->profile = false;
-    S->raw_valid = S->last_outer > 0; S->raw_is_diag = use_diag != 0;
-    S->has_valid_keff = 1; S->last_keff = keff;                   // :1808-1809
+    if (T->profile) prof_collect(T);
+    T->profile = false;
+    for (auto *S : T->slabs) { S->raw_valid = T->last_outer > 0; S->raw_is_diag = use_diag != 0; }
+    T->has_valid_keff = 1; T->last_keff = keff;                   // :1808-1809
     if (keff_out) *keff_out = keff;
-    if (n_outer) *n_outer = S->last_outer;
+    if (n_outer) *n_outer = T->last_outer;
     return NF_OK;
 }
 
 int nf_solve_keff(nf_handle S, const nf_keff_opts *o, double *keff, int *n_outer)
 {
     if (!S || !o) return fail(NF_ERR_ARG, "nf_solve_keff: bad arguments");
-    if (!S->built) return fail(NF_ERR_STATE, "nf_solve_keff: call nf_build first");
+    for (auto *X : S->team->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_solve_keff: call nf_build first");
     HIPCHK(hipSetDevice(S->device));
-    return solve_keff_impl(S, o, keff, n_outer);
+    return solve_keff_impl(S->team, o, keff, n_outer);
 }
 
 int nf_get_history(nf_handle S, double *k, double *dk, double *dphi, int *cg, int cap)
 {
     if (!S) return fail(NF_ERR_ARG, "null handle");
-    const int n = std::min<int>(cap, S->last_outer);
+    nf_team *T = S->team;
+    const int n = std::min<int>(cap, T->last_outer);
     for (int i = 0; i < n; ++i) {
-        if (k) k[i] = S->hist_k[i];
-        if (dk) dk[i] = S->hist_dk[i];
-        if (dphi) dphi[i] = S->hist_dphi[i];
-        if (cg) for (int g = 0; g < S->ng; ++g) cg[i * S->ng + g] = S->hist_cg[i * S->ng + g];
+        if (k) k[i] = T->hist_k[i];
+        if (dk) dk[i] = T->hist_dk[i];
+        if (dphi) dphi[i] = T->hist_dphi[i];
+        if (cg) for (int g = 0; g < S->ng; ++g) cg[i * S->ng + g] = T->hist_cg[i * S->ng + g];
     }
     return NF_OK;
 }
@@ -685,28 +1048,34 @@ int nf_get_history(nf_handle S, double *k, double *dk, double *dphi, int *cg, in
 int nf_profile_get(nf_handle S, const char *name, long *count, double *total_ms)
 {
     if (!S || !name) return fail(NF_ERR_ARG, "nf_profile_get: bad arguments");
-    auto it = S->prof.find(name);
-    if (count) *count = it == S->prof.end() ? 0 : it->second.count;
-    if (total_ms) *total_ms = it == S->prof.end() ? 0.0 : it->second.ms;
+    auto it = S->team->prof.find(name);
+    if (count) *count = it == S->team->prof.end() ? 0 : it->second.count;
+    if (total_ms) *total_ms = it == S->team->prof.end() ? 0.0 : it->second.ms;
     return NF_OK;
 }
-int nf_profile_reset(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->prof.clear(); return NF_OK; }
+int nf_profile_reset(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->team->prof.clear(); return NF_OK; }
 
 int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
 {
     if (!S || g < 0 || g >= S->ng || reps < 1 || !avg_ms) return fail(NF_ERR_ARG, "nf_time_schur_apply: bad arguments");
-    if (!S->built) return fail(NF_ERR_STATE, "nf_time_schur_apply: call nf_build first");
+    nf_team *T = S->team;
+    for (auto *X : T->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_time_schur_apply: call nf_build first");
     HIPCHK(hipSetDevice(S->device));
-    hipLaunchKernelGGL(k_fill_pattern, dim3(grid_for(S->N)), dim3(256), 0, S->stream, S->d_p, S->N);
-    NFCHK(schur_apply(S, g, S->d_p, S->d_q, nullptr, nullptr, nullptr));   // warm-up
-    S->profile = true;
-    for (int i = 0; i < std::min(reps, 8); ++i) NFCHK(schur_apply(S, g, S->d_p, S->d_q, nullptr, nullptr, nullptr));
-    HIPCHK(hipStreamSynchronize(S->stream));
-    prof_collect(S); S->profile = false;
+    NFCHK(team_prepare(T));
+    std::vector<const double *> xs; std::vector<double *> ys;
+    for (auto *X : T->slabs) {
+        hipLaunchKernelGGL(k_fill_pattern, dim3(grid_for(X->N)), dim3(256), 0, T->stream, X->d_p, X->N);
+        xs.push_back(X->d_p); ys.push_back(X->d_q);
+    }
+    NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));   // warm-up
+    T->profile = true;
+    for (int i = 0; i < std::min(reps, 8); ++i) NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));
+    HIPCHK(hipStreamSynchronize(T->stream));
+    prof_collect(T); T->profile = false;
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    HIPCHK(hipEventRecord(a, S->stream));
-    for (int i = 0; i < reps; ++i) NFCHK(schur_apply(S, g, S->d_p, S->d_q, nullptr, nullptr, nullptr));
-    HIPCHK(hipEventRecord(b, S->stream));
+    HIPCHK(hipEventRecord(a, T->stream));
+    for (int i = 0; i < reps; ++i) NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));
+    HIPCHK(hipEventRecord(b, T->stream));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
@@ -717,10 +1086,11 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
 int nf_set_option(nf_handle S, const char *key, long value)
 {
     if (!S || !key) return fail(NF_ERR_ARG, "nf_set_option: bad arguments");
-    if (!strcmp(key, "s_tx")) S->opt_s_tx = (int)value;
-    else if (!strcmp(key, "s_seg")) S->opt_s_seg = (int)value;
-    else if (!strcmp(key, "s_pair")) S->opt_s_pair = (int)value;
-    else if (!strcmp(key, "cg_batch")) S->cg_batch = (int)value;
+    nf_team *T = S->team;
+    if (!strcmp(key, "s_tx")) T->opt_s_tx = (int)value;
+    else if (!strcmp(key, "s_seg")) T->opt_s_seg = (int)value;
+    else if (!strcmp(key, "s_pair")) T->opt_s_pair = (int)value;
+    else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
 }
@@ -740,7 +1110,7 @@ int nf_memcpy_h2d(nf_handle S, void *dst, const void *src, size_t bytes)
 int nf_memcpy_d2h(nf_handle S, void *dst, const void *src, size_t bytes)
 {
     if (!S || !dst || !src) return fail(NF_ERR_ARG, "nf_memcpy_d2h: bad arguments");
-    HIPCHK(hipSetDevice(S->device)); HIPCHK(hipStreamSynchronize(S->stream)); HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return NF_OK;
+    HIPCHK(hipSetDevice(S->device)); HIPCHK(hipStreamSynchronize(S->team->stream)); HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return NF_OK;
 }
-int nf_synchronize(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); HIPCHK(hipSetDevice(S->device)); HIPCHK(hipStreamSynchronize(S->stream)); return NF_OK; }
-void *nf_stream(nf_handle S) { return S ? (void *)S->stream : nullptr; }
+int nf_synchronize(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); HIPCHK(hipSetDevice(S->device)); HIPCHK(hipStreamSynchronize(S->team->stream)); HIPCHK(hipDeviceSynchronize()); return NF_OK; }
+void *nf_stream(nf_handle S) { return S ? (void *)S->team->stream : nullptr; }

@@ -22,8 +22,6 @@ struct CgScalars {
     int done, its, maxit, pad;
 };
 
-enum FinOp { FIN_RHS = 0, FIN_PAP = 1, FIN_RR = 2, FIN_SUM = 3 };
-
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -47,21 +45,12 @@ __device__ __forceinline__ double block_sum(double v, double *sred)
 
 // ---------------------------------------------------------------------------------------------
 // second reduction stage + CG scalar logic.  One block of 256 threads.
-// partials: nq rows of `stride` doubles, `count` valid entries each.
-__global__ __launch_bounds__(256) void k_finalize(int op, const double *__restrict__ partials, int count, long stride,
-                                                  int nq, CgScalars *__restrict__ cg, double *__restrict__ out,
-                                                  double tol, int maxit)
+// partials: nq rows of `stride` doubles; each local slab owns a segment [off, off+cnt) of every row.
+struct PartSegs { int n; int off[16]; int cnt[16]; };
+enum FinOp { FIN_RHS = 0, FIN_PAP = 1, FIN_RR = 2, FIN_SUM = 3 };
+
+__device__ __forceinline__ void cg_logic(int op, const double *tot, int nq, CgScalars *cg, double *out, double tol, int maxit)
 {
-    __shared__ double sred[4];
-    if (op == FIN_PAP || op == FIN_RR) { if (cg->done) return; }
-    double tot[4] = { 0, 0, 0, 0 };
-    for (int q = 0; q < nq; ++q) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < count; i += 256) s += partials[q * stride + i];
-        s = block_sum(s, sred);
-        tot[q] = s;
-    }
-    if (threadIdx.x != 0) return;
     if (op == FIN_RHS) {                       // src/solvers.cpp:587-592
         cg->rr = tot[0];
         cg->rhs_norm = sqrt(tot[0]);
@@ -85,6 +74,37 @@ __global__ __launch_bounds__(256) void k_finalize(int op, const double *__restri
     } else {
         for (int q = 0; q < nq; ++q) out[q] = tot[q];
     }
+}
+
+// reduce_only = 1: write the process-local sums to red[] (an all-reduce over ranks follows, then k_cg_logic)
+__global__ __launch_bounds__(256) void k_finalize(int op, const double *__restrict__ partials, PartSegs segs, long stride,
+                                                  int nq, CgScalars *__restrict__ cg, double *__restrict__ out,
+                                                  double tol, int maxit, int reduce_only, double *__restrict__ red)
+{
+    __shared__ double sred[4];
+    if (op == FIN_PAP || op == FIN_RR) { if (cg->done) return; }
+    double tot[4] = { 0, 0, 0, 0 };
+    for (int q = 0; q < nq; ++q) {
+        double acc = 0.0;
+        for (int sgi = 0; sgi < segs.n; ++sgi) {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < segs.cnt[sgi]; i += 256) s += partials[q * stride + segs.off[sgi] + i];
+            s = block_sum(s, sred);
+            acc += s;
+        }
+        tot[q] = acc;
+    }
+    if (threadIdx.x != 0) return;
+    if (reduce_only) { for (int q = 0; q < nq; ++q) red[q] = tot[q]; return; }
+    cg_logic(op, tot, nq, cg, out, tol, maxit);
+}
+__global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgScalars *__restrict__ cg, double *__restrict__ out,
+                           double tol, int maxit)
+{
+    if (op == FIN_PAP || op == FIN_RR) { if (cg->done) return; }
+    double tot[4] = { 0, 0, 0, 0 };
+    for (int q = 0; q < nq; ++q) tot[q] = red[q];
+    cg_logic(op, tot, nq, cg, out, tol, maxit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,8 +160,16 @@ __device__ __forceinline__ void cell_a(const Geom &G, int d, int ix, int iy, int
 // for one direction: one thread per grid line assembles the tridiagonal T of that line on the fly
 // and stores its LDL^T factor cell-aligned: L[e] couples the lower to the upper face of cell e,
 // DR[e] = 1/d'(upper face of e), D0[line] = 1/d'(first face).
+// Slab decomposition (z lines only): if_lo / if_hi mark an interface with the neighbouring slab.  The
+// interface face is a separator (partition method); the factored chain then covers the interior faces
+// only: cells [fs, n-fe_off) with the edge cell's a2 added to the first/last chain diagonal.  Per line it
+// also emits what the reduced (separator) system needs: alo/ahi = coupling a1 of the edge cells and
+// hlo/hhi = this slab's half of the separator diagonal, a2_edge - a1_edge^2 (T_II^-1)[end,end].
+// gfl = a1_lo a1_hi (T_II^-1)[first,last] measures the separator-to-separator coupling through the slab.
+struct SlabOut { double *alo, *ahi, *hlo, *hhi, *gfl; };
 __global__ void k_factor_lines(Geom G, int d, const double *__restrict__ D, double *__restrict__ L,
-                               double *__restrict__ DR, double *__restrict__ D0, long nlines)
+                               double *__restrict__ DR, double *__restrict__ D0, long nlines, int if_lo, int if_hi,
+                               SlabOut so)
 {
     const long line = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (line >= nlines) return;
@@ -151,19 +179,29 @@ __global__ void k_factor_lines(Geom G, int d, const double *__restrict__ D, doub
     else if (d == 1) { n = G.ny; ix = (int)(line % G.nx); iz = (int)(line / G.nx); base = iz * nxy + ix; sl = G.nx; }
     else { n = G.nz; ix = (int)(line % G.nx); iy = (int)(line / G.nx); base = line; sl = nxy; }
     int *ci = d == 0 ? &ix : d == 1 ? &iy : &iz;
-    *ci = 0;
-    double Dc = D[base], a2, a1;
+    const int fs = if_lo ? 1 : 0, ce = if_hi ? n - 1 : n;       // chain cells [fs, ce)
+    double a2, a1, ea2, ea1;
+    // first chain face: lower contribution = Dirichlet term or the edge cell below
+    *ci = fs;
+    double Dc = D[base + (long)fs * sl];
     cell_a(G, d, ix, iy, iz, Dc, a2, a1);
-    double dprev = a2 + (G.dir_lo[d] ? dirichlet_term(G, d, ix, iy, iz, Dc) : 0.0);
+    double dprev;
+    double alo = 0.0, a2lo = 0.0;
+    if (if_lo) { *ci = 0; cell_a(G, d, ix, iy, iz, D[base], ea2, ea1); alo = ea1; a2lo = ea2; dprev = ea2 + a2; }
+    else { *ci = fs; dprev = a2 + (G.dir_lo[d] ? dirichlet_term(G, d, ix, iy, iz, Dc) : 0.0); }
+    double ahi = 0.0, a2hi = 0.0;
+    if (if_hi) { *ci = n - 1; cell_a(G, d, ix, iy, iz, D[base + (long)(n - 1) * sl], ea2, ea1); ahi = ea1; a2hi = ea2; }
     D0[line] = 1.0 / dprev;
-    for (int c = 0; c < n; ++c) {
-        double diag_next;
-        double na2 = 0.0, na1 = 0.0;
-        if (c + 1 < n) {
+    double prodl = 1.0, g00 = 1.0 / dprev;                      // (T^-1)[0,0] = sum_k (prod_{j<k} l_j)^2 / d'_k
+    for (int c = fs; c < ce; ++c) {
+        double diag_next, na2 = 0.0, na1 = 0.0;
+        if (c + 1 < ce) {
             *ci = c + 1;
             const double Dn = D[base + (long)(c + 1) * sl];
             cell_a(G, d, ix, iy, iz, Dn, na2, na1);
             diag_next = a2 + na2;
+        } else if (if_hi) {
+            diag_next = a2 + a2hi;
         } else {
             *ci = c;
             diag_next = a2 + (G.dir_hi[d] ? dirichlet_term(G, d, ix, iy, iz, Dc) : 0.0);
@@ -172,9 +210,37 @@ __global__ void k_factor_lines(Geom G, int d, const double *__restrict__ D, doub
         const double dn = diag_next - l * a1;
         L[base + (long)c * sl] = l;
         DR[base + (long)c * sl] = 1.0 / dn;
+        prodl *= -l; g00 += prodl * prodl / dn;
         dprev = dn;
-        if (c + 1 < n) { Dc = D[base + (long)(c + 1) * sl]; a2 = na2; a1 = na1; }
+        if (c + 1 < ce) { Dc = D[base + (long)(c + 1) * sl]; a2 = na2; a1 = na1; }
     }
+    if (if_lo) { L[base] = 0.0; DR[base] = 0.0; }
+    if (if_hi) { L[base + (long)(n - 1) * sl] = 0.0; DR[base + (long)(n - 1) * sl] = 0.0; }
+    if (so.alo) {
+        so.alo[line] = alo; so.ahi[line] = ahi;
+        so.hlo[line] = a2lo - alo * alo * g00;
+        so.hhi[line] = a2hi - ahi * ahi / dprev;                 // (T^-1)[last,last] = 1/d'_last
+        so.gfl[line] = alo * ahi * prodl / dprev;
+    }
+}
+
+// separator values of the partition method: u = (own contribution + neighbour's) / S_red   (slab interfaces)
+__global__ void k_separators(const double *__restrict__ clo, const double *__restrict__ chi, const double *__restrict__ rlo,
+                             const double *__restrict__ rhi, const double *__restrict__ sinv_lo, const double *__restrict__ sinv_hi,
+                             double *__restrict__ ulo, double *__restrict__ uhi, long nlines, int if_lo, int if_hi,
+                             const CgScalars *__restrict__ cg)
+{
+    if (cg && cg->done) return;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    if (if_lo) ulo[i] = (rlo[i] + clo[i]) * sinv_lo[i];          // below's c_hi + own c_lo (same order on both sides)
+    if (if_hi) uhi[i] = (chi[i] + rhi[i]) * sinv_hi[i];          // own c_hi + above's c_lo
+}
+// S_red^-1 from the two halves (own + neighbour's)
+__global__ void k_sred_inv(const double *__restrict__ own, const double *__restrict__ other, double *__restrict__ out, long n, int own_first)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 1.0 / (own_first ? own[i] + other[i] : other[i] + own[i]);
 }
 
 // BuildDiagonalSchurCache (src/NeutFEM.cpp:483-597): S_inv(e) = 1/(C_ee + sum_faces B_ef^2 / A_ff)
@@ -337,11 +403,21 @@ __global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, d
 // the segment held in registers; segment summaries (affine maps) are exchanged through LDS.
 // Always accumulates into y (the x pass ran first).  Grid: (ceil(nx/TX), n_outer).
 // DIR (1 = y, 2 = z) only tags the instantiation so profilers list the two passes separately.
-template <int SEG, int DIR>
+// SLAB = true (z lines of a slab with interfaces): the kernel works on the interior chain of the
+// slab-local line.  mode 1 = endpoint response (partition method, step 1): solve with the plain
+// neighbour cells as boundary data, emit c_lo = -beta x_edge - a_lo u_first, c_hi = beta x_edge - a_hi u_last,
+// touch no y.  mode 2 = final solve with the separator values u_lo/u_hi folded into the boundary data,
+// accumulate y on the chain cells and on the edge cells.
+struct SlabArgs {
+    int if_lo, if_hi, mode;
+    const double *alo, *ahi, *ulo, *uhi;      // per line
+    double *clo, *chi;                        // per line (mode 1 outputs)
+};
+template <int SEG, int DIR, bool SLAB>
 __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ L,
                           const double *__restrict__ DR, const double *__restrict__ D0, int n, long sl,
                           long outer_stride, int nx, int TX, int NSEG, double beta, int last,
-                          double *__restrict__ partials, const CgScalars *__restrict__ cg)
+                          double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa)
 {
     extern __shared__ double sm[];
     if (cg && cg->done) return;
@@ -350,7 +426,23 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
     const int tid = threadIdx.x, ixl = tid % TX, seg = tid / TX;
     const int ix = blockIdx.x * TX + ixl;
     const bool valid = ix < nx;
-    const long base = (long)blockIdx.y * outer_stride + ix;
+    long base = (long)blockIdx.y * outer_stride + ix;
+    const long lineid = (long)blockIdx.y * nx + ix;
+    // slab chain: cells [fs, fs+n) of the local line; x just outside the chain is real data (edge cells)
+    double x_before = 0.0, x_after = 0.0, a_lo = 0.0, a_hi = 0.0, u_lo = 0.0, u_hi = 0.0;
+    long edge_lo = 0, edge_hi = 0;
+    if (SLAB) {
+        const int fs = sa.if_lo ? 1 : 0;
+        const int nloc = n;                                      // local cells on the line
+        n = nloc - fs - (sa.if_hi ? 1 : 0);
+        edge_lo = base; edge_hi = base + (long)(nloc - 1) * sl;
+        base += (long)fs * sl;
+        if (valid) {
+            if (sa.if_lo) { a_lo = sa.alo[lineid]; x_before = x[edge_lo]; if (sa.mode == 2) { u_lo = sa.ulo[lineid]; x_before -= (a_lo / beta) * u_lo; } }
+            if (sa.if_hi) { a_hi = sa.ahi[lineid]; x_after = x[edge_hi]; if (sa.mode == 2) { u_hi = sa.uhi[lineid]; x_after += (a_hi / beta) * u_hi; } }
+        }
+    }
+    const bool wr = !SLAB || sa.mode == 2;
     const int c0 = seg * SEG;
     double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];
 #pragma unroll
@@ -358,17 +450,18 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
         xv[i] = ok ? x[a] : 0.0;
+        if (SLAB && valid && c == n) xv[i] = x_after;
         Lv[i] = ok ? L[a] : 0.0;
-        if (i < SEG) { Rv[i] = ok ? DR[a] : 0.0; yo[i] = ok ? y[a] : 0.0; }
+        if (i < SEG) { Rv[i] = ok ? DR[a] : 0.0; yo[i] = (ok && wr) ? y[a] : 0.0; }
     }
     double dinv_s = 0.0;
-    if (valid && c0 < n) dinv_s = c0 == 0 ? D0[(long)blockIdx.y * nx + ix] : DR[base + (long)(c0 - 1) * sl];
+    if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
     double t[SEG];
     double P = 1.0, lz = 0.0;
 #pragma unroll
     for (int i = 0; i < SEG; ++i) { t[i] = beta * (xv[i] - xv[i + 1]); lz = t[i] - Lv[i] * lz; P = -Lv[i] * P; }
     sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz;
-    if (seg == 0) sZ0[ixl] = -beta * xv[0];
+    if (seg == 0) sZ0[ixl] = beta * (x_before - xv[0]);
     __syncthreads();
     double z = sZ0[ixl];
     for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
@@ -385,13 +478,30 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
     for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { u = w[i] - Lv[i + 1] * u; w[i] = u; }
-    const double ulo = zin * dinv_s - Lv[0] * w[0];
+    const double ulo = zin * dinv_s - Lv[0] * w[0];             // u at the lower face of this segment
     double dot = 0.0;
+    if (wr) {
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-        const double yv = yo[i] + beta * (w[i] - (i == 0 ? ulo : w[i > 0 ? i - 1 : 0]));
-        const int c = c0 + i;
-        if (valid && c < n) { y[base + (long)c * sl] = yv; dot += xv[i] * yv; }
+        for (int i = 0; i < SEG; ++i) {
+            const double yv = yo[i] + beta * (w[i] - (i == 0 ? ulo : w[i > 0 ? i - 1 : 0]));
+            const int c = c0 + i;
+            if (valid && c < n) { y[base + (long)c * sl] = yv; dot += xv[i] * yv; }
+        }
+    }
+    if (SLAB) {
+        // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1
+        if (valid && seg == 0 && sa.if_lo) {
+            if (sa.mode == 1) sa.clo[lineid] = -beta * x[edge_lo] - a_lo * ulo;
+            else { const double xe = x[edge_lo]; const double yv = y[edge_lo] + beta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv; }
+        }
+        if (valid && sa.if_hi && c0 <= n - 1 && n - 1 < c0 + SEG) {
+            double ulast = 0.0;
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) if (c0 + i == n - 1) ulast = w[i];
+            if (n == 0) ulast = ulo;
+            if (sa.mode == 1) sa.chi[lineid] = beta * x[edge_hi] - a_hi * ulast;
+            else { const double xe = x[edge_hi]; const double yv = y[edge_hi] + beta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv; }
+        }
     }
     if (last && partials) {
         const double s = block_sum(dot, sred);

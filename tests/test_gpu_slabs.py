@@ -1,0 +1,95 @@
+"""GPU tests of the z-slab decomposition in loopback (all slabs of the team on the one GPU of the test box):
+the partition-method z-line solve, the team CG and the team power iteration against the undivided HIP solve and
+the oracle.  The RCCL transport itself (ncclSend/Recv/AllReduce between processes) cannot run here -- RCCL refuses
+two ranks on one device -- and is exercised by the driver's multi-GPU bench."""
+import numpy as np
+import pytest
+
+from helpers import make_hip, make_oracle, rel_l2, synthetic_inputs
+from neutfem_amd.capi import HipTeam
+
+pytestmark = pytest.mark.gpu
+
+
+def make_team(inp, planes):
+    t = HipTeam(0, 0, int(inp["ng"]), inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], planes)
+    t.set_linear_solver(6)
+    for a, ty in zip(inp["bc_attr"], inp["bc_type"]):
+        t.set_bc(int(a), int(ty))
+    t.upload_xs_global(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"])
+    t.build()
+    return t
+
+
+@pytest.mark.parametrize("shape,planes", [((12, 10, 9), [(0, 4), (4, 9)]),               # 2 slabs: exact for any thickness
+                                          ((16, 8, 70), [(0, 35), (35, 70)]),
+                                          ((8, 6, 100), [(0, 33), (33, 67), (67, 100)]),   # middle slab of 34 planes
+                                          ((20, 12, 128), [(0, 32), (32, 64), (64, 96), (96, 128)]),
+                                          ((37, 9, 66), [(0, 3), (3, 66)])])               # thinnest legal edge slab, odd nx
+def test_team_schur_apply_matches_undivided(shape, planes):
+    nx, ny, nz = shape
+    inp = synthetic_inputs(nx, ny, nz, 2, seed=nz, dirichlet=(1, 2, 3, 4, 5, 6) if nz % 2 == 0 else (1, 3, 6))
+    o, t = make_oracle(inp), make_team(inp, planes)
+    rng = np.random.default_rng(4)
+    for g in range(2):
+        x = rng.standard_normal((nz, ny, nx))
+        y = t.schur_apply(g, x)
+        assert rel_l2(y.ravel(), o.schur_apply(g, x.ravel())) < 1e-12
+    t.close()
+
+
+def test_thin_middle_slab_is_refused():
+    inp = synthetic_inputs(8, 8, 30, 1, seed=2)
+    t = make_team(inp, [(0, 10), (10, 20), (20, 30)])
+    with pytest.raises(RuntimeError, match="too thin"):
+        t.schur_apply(0, np.ones((30, 8, 8)))
+    t.close()
+
+
+@pytest.mark.parametrize("planes", [[(0, 48), (48, 96)], [(0, 32), (32, 64), (64, 96)]])
+def test_team_solve_keff_matches_undivided_and_oracle(planes):
+    inp = synthetic_inputs(14, 12, 96, 2, seed=9)
+    tol = (1e-11, 1e-11, 1e-11, 1000, 2000)
+    o, s, t = make_oracle(inp), make_hip(inp), make_team(inp, planes)
+    o.set_tol(*tol); s.set_tol(*tol); t.set_tol(*tol)
+    ko = o.SolveKeff(); ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
+    phi_t = t.get_phi_local().ravel()
+    assert abs(kt - ks) / ks < 1e-10 and abs(kt - ko) / ko < 1e-9
+    assert rel_l2(phi_t, s.get_phi().ravel()) < 1e-8
+    assert rel_l2(phi_t, o.phi_dofs().ravel()) < 1e-8
+    assert abs(nt - ns) <= 1
+    # same algorithm, only the summation order of the dot products differs: CG counts within 2 %
+    hs, ht = s.history()["cg"][:min(ns, nt)], t.history()["cg"][:min(ns, nt)]
+    assert np.abs(ht - hs).max() <= 0.02 * hs.max()
+    s.close(); t.close()
+
+
+def test_team_driver_tolerances_iaea3d_like():
+    """reference-driver tolerances on a resampled IAEA-3D core cut into 2 slabs"""
+    from neutfem_amd import cases
+    c = cases.iaea3d_resampled(38, 76)
+    inp = dict(x_breaks=c["x_breaks"], y_breaks=c["y_breaks"], z_breaks=c["z_breaks"], D=c["D"], SigR=c["SigR"], NSF=c["NSF"],
+               Chi=c["Chi"], SigS=c["SigS"], bc_attr=np.array([a for a, _ in c["bc"]]), bc_type=np.array([t for _, t in c["bc"]]), ng=2)
+    s, t = make_hip(inp), make_team(inp, [(0, 38), (38, 76)])
+    tol = (1e-5, 1e-4, 1e-4, 200, 1000)
+    s.set_tol(*tol); t.set_tol(*tol)
+    ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
+    assert abs(kt - ks) / ks < 1e-5 and abs(nt - ns) <= 1
+    assert rel_l2(t.get_phi_local().ravel(), s.get_phi().ravel()) < 2e-4
+    s.close(); t.close()
+
+
+def test_rccl_allreduce_path_single_rank(monkeypatch):
+    """NEUTFEM_FORCE_RCCL=1 builds a real 1-rank RCCL communicator and routes every scalar reduction of the solve
+    through ncclAllReduce on the solver's stream (what one cannot test here is ncclSend/ncclRecv between ranks)."""
+    from neutfem_amd.capi import HipTeam
+    monkeypatch.setenv("NEUTFEM_FORCE_RCCL", "1")
+    inp = synthetic_inputs(16, 12, 80, 2, seed=3)
+    s, t = make_hip(inp), make_team(inp, [(0, 40), (40, 80)])
+    t.comm_init(HipTeam.unique_id(), 1, 0)
+    tol = (1e-10, 1e-10, 1e-10, 500, 2000)
+    s.set_tol(*tol); t.set_tol(*tol)
+    ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
+    assert abs(kt - ks) / ks < 1e-10 and abs(nt - ns) <= 1
+    assert rel_l2(t.get_phi_local().ravel(), s.get_phi().ravel()) < 1e-8
+    s.close(); t.close()
