@@ -71,7 +71,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,shape", [(2, (7, 6, 12)), (3, (4, 3, 99)), (2, (5, 4, 7))])
+@pytest.mark.parametrize("world,shape", [(2, (7, 6, 12)), (3, (4, 3, 99)), (2, (5, 6, 7))])
 def test_slab_partition_method_gloo(world, shape, tmp_path):
     out = str(tmp_path / "res.npy")
     mp.spawn(_worker, args=(world, _free_port(), shape, 11, out), nprocs=world, join=True)
