@@ -10,7 +10,8 @@
  * Layouts (identical to the reference's flat arrays, include/NeutFEM.hpp:365-388):
  *   cell e = iz*nx*ny + iy*nx + ix                       (src/FEM.cpp:89-91)
  *   XS      [g*N + e]            SigS [(g_to*ng + g_from)*N + e]
- *   phi     [g*n_phi + e*n_loc + l]                      (n_loc = 1 for P0)
+ *   phi     [g*n_phi + e*n_loc + l]                      (n_loc = 1 for P0)   host arrays (nf_set_phi/nf_get_phi)
+ *   *_dev vectors (nf_schur_apply, nf_solve_group): device DOF order [l*N + e] (moment-major; same thing for P0)
  *   J       [g*n_J + f]   faces x | y | z | bubbles      (src/FEM.cpp:264-334)
  */
 #ifndef NEUTFEM_HIP_H

@@ -125,7 +125,7 @@ class HipSolver:
         else:
             self._chk(self.L.nf_create(rt_order, p_order, ng, len(xb), _dp(xb), len(yb), _dp(yb), len(zb), _dp(zb), device, C.byref(h)))
         self.h = h
-        for key in ("dim", "nx", "ny", "nz", "ne", "ng", "n_phi", "n_J"):
+        for key in ("dim", "nx", "ny", "nz", "ne", "ng", "n_phi", "n_J", "n_loc"):
             setattr(self, key, self.L.nf_info(h, key.encode()))
         self.tol = (1e-5, 1e-5, 1e-5, 200, 1000)
         self.solver_type, self.solver_pushed = 6, 0
@@ -158,17 +158,21 @@ class HipSolver:
     def build(self): self._chk(self.L.nf_build(self.h))
     def vector(self, n=None): return DeviceVector(self, n or self.n_phi)
 
+    # *_dev vectors of the C ABI use the device DOF order [p*N + e]; these helpers take / return the reference order [e*n_loc + p]
+    def _to_dev(self, v): return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(self.ne, self.n_loc).T).ravel()
+    def _from_dev(self, v): return np.ascontiguousarray(v.reshape(self.n_loc, self.ne).T).ravel()
+
     def schur_apply(self, g, x):
-        xd, yd = self.vector().upload(x), self.vector()
+        xd, yd = self.vector().upload(self._to_dev(x)), self.vector()
         self._chk(self.L.nf_schur_apply(self.h, g, xd.ptr, yd.ptr))
-        y = yd.download(); xd.free(); yd.free()
+        y = self._from_dev(yd.download()); xd.free(); yd.free()
         return y
 
     def solve_group(self, g, rhs, tol, maxit):
-        bd, xd = self.vector().upload(rhs), self.vector()
+        bd, xd = self.vector().upload(self._to_dev(rhs)), self.vector()
         its, res = C.c_int(), C.c_double()
         self._chk(self.L.nf_solve_group(self.h, g, bd.ptr, xd.ptr, tol, maxit, C.byref(its), C.byref(res)))
-        x = xd.download(); bd.free(); xd.free()
+        x = self._from_dev(xd.download()); bd.free(); xd.free()
         return x, its.value, res.value
 
     def opts(self, use_coarse=False, factors=(), use_diag=False, profile=False):

@@ -101,7 +101,7 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
-    int opt_s_tx = 0, opt_s_seg = 0, opt_s_pair = 0;      // tuning overrides (nf_set_option)
+    int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
 
 struct nf_solver {
@@ -111,7 +111,8 @@ struct nf_solver {
     int if_lo = 0, if_hi = 0;                            // interface with the slab below / above (z)
     // mesh (of this slab)
     int dim = 1, nx = 1, ny = 1, nz = 1, ng = 1, k = 0, m = 0;
-    long N = 0, nJ = 0, nJx = 0, nJy = 0, nJz = 0;
+    int n1 = 1, nloc = 1, nb = 0;                        // P moments per axis, per cell; bubble moments present in P_m
+    long N = 0, nphi = 0, nJ = 0, nJx = 0, nJy = 0, nJz = 0;   // nphi = nloc * N DOFs per group (device layout [p][e])
     std::vector<double> xb, yb, zb, hx, hy, hz;
     double *d_hx = nullptr, *d_hy = nullptr, *d_hz = nullptr, *d_xb = nullptr, *d_yb = nullptr, *d_zb = nullptr;
     int bc_set[8] = {0}, bc_type[8] = {0};
@@ -157,9 +158,13 @@ static const char *SLOT_NAMES[5] = { "schur_x", "schur_y", "schur_z", "schur_app
 
 static Geom make_geom(const nf_solver *S)
 {
-    Geom G; G.dim = S->dim; G.nx = S->nx; G.ny = S->ny; G.nz = S->nz; G.hx = S->d_hx; G.hy = S->d_hy; G.hz = S->d_hz;
-    const double p2 = (double)(1 << (S->dim - 1));
-    G.cLL = p2 * 2.0 / 3.0; G.cLR = p2 / 3.0; G.beta = p2;
+    Geom G; G.dim = S->dim; G.nx = S->nx; G.ny = S->ny; G.nz = S->nz; G.k = S->k; G.hx = S->d_hx; G.hy = S->d_hy; G.hz = S->d_hz;
+    G.T0 = (double)(1 << (S->dim - 1));
+    // face block of the 1-D element matrix after condensing the k bubbles (exact values of the reference's Gauss
+    // quadrature, src/FEM.cpp:891-924): M^FF - M^Fb (M^bb)^-1 M^bF
+    if (S->k == 0) { G.aLL = 2.0 / 3.0; G.aLR = 1.0 / 3.0; }
+    else if (S->k == 1) { G.aLL = 1.0 / 4.0; G.aLR = -1.0 / 12.0; }
+    else { G.aLL = 2.0 / 15.0; G.aLR = 1.0 / 30.0; }
     // GetBoundaryAttribute, src/NeutFEM.cpp:2338-2347
     for (int d = 0; d < 3; ++d) {
         int lo, hi;
@@ -179,10 +184,41 @@ static int grid_for(long n, int block = 256, int cap = RED_GRID)
     long g = (n + block - 1) / block; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g;
 }
 
+// transverse Legendre modes of one direction that couple to phi: a in [0,m]^(dim-1)
+static int n_modes(const nf_solver *S) { int n = 1; for (int t = 1; t < S->dim; ++t) n *= S->n1; return n; }
+// moment index p = i_x + n1 i_y + n1^2 i_z of (along-index i, transverse mode `mode`) for direction d, and T_a
+static int moment_index(const nf_solver *S, int d, int mode, int i, double *Ta)
+{
+    const int n1 = S->n1;
+    int idx[3] = {0, 0, 0}; double ta = 1.0; int q = mode;
+    for (int t = 0; t < S->dim; ++t) {
+        if (t == d) { idx[t] = i; continue; }
+        idx[t] = q % n1; q /= n1;
+        ta *= 2.0 / (2.0 * idx[t] + 1.0);
+    }
+    if (Ta) *Ta = ta;
+    return idx[0] + n1 * idx[1] + n1 * n1 * idx[2];
+}
+// per-pass constants + moment pointers (ModeArgs) for direction d, mode `mode`; xb/yb: SoA vectors of nphi doubles
+static ModeArgs mode_args(const nf_solver *S, int g, int d, int mode, const double *xb, double *yb)
+{
+    ModeArgs ma; memset(&ma, 0, sizeof ma);
+    double Ta = 1.0;
+    for (int i = 0; i <= S->nb; ++i) {
+        const int p = moment_index(S, d, mode, i, &Ta);
+        ma.x[i] = xb + (long)p * S->N; ma.y[i] = yb + (long)p * S->N; ma.Cd[i] = S->d_Cd + (long)g * S->nphi + (long)p * S->N;
+    }
+    ma.Ta = Ta; ma.dir = d; ma.D = S->d_D + (long)g * S->N;
+    // bubble l: eL/eR = M^Fb_{L/R,l} / M^bb_l, Gc = int P_{l+1} d/dxi[(1-xi^2) P_l], iM = 1 / M^bb_l  (src/FEM.cpp:377-620)
+    ma.eL[0] = 5.0 / 8.0; ma.eR[0] = 5.0 / 8.0; ma.Gc[0] = -4.0 / 3.0; ma.iM[0] = 15.0 / 16.0;
+    ma.eL[1] = -7.0 / 8.0; ma.eR[1] = 7.0 / 8.0; ma.Gc[1] = -4.0 / 5.0; ma.iM[1] = 105.0 / 16.0;
+    return ma;
+}
+
 // ---- team management ---------------------------------------------------------------------------
 static long slab_partial_need(const nf_solver *S)
 {
-    return std::max<long>(RED_GRID, std::max(S->nlines[0], (long)((S->nx + 7) / 8) * std::max(S->ny, S->nz))) + 16;
+    return (std::max<long>(RED_GRID, std::max(S->nlines[0], (long)((S->nx + 7) / 8) * std::max(S->ny, S->nz))) + 16) * n_modes(S);
 }
 static int team_alloc(nf_team *T)
 {
@@ -221,8 +257,8 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     if (!out || !xb || nxb < 2 || ng < 1 || ng > 64) return fail(NF_ERR_ARG, "nf_create: bad arguments");
     int k = std::min(rt_order, 2), m = std::min(p_order, 2);
     if (k < m) m = k;                                            // src/NeutFEM.cpp:149-169
-    if (k != 0 || m != 0)
-        return fail(NF_ERR_UNSUPPORTED, "nf_create: RT%d-P%d is not implemented on the HIP path yet (RT0-P0 only)", k, m);
+    if ((if_lo || if_hi) && (k != 0 || m != 0))
+        return fail(NF_ERR_UNSUPPORTED, "slab decomposition is implemented for RT0-P0 only (asked RT%d-P%d)", k, m);
     int ndev = nf_device_count();
     if (ndev <= 0) return fail(NF_ERR_NO_DEVICE, "nf_create: no HIP device visible (the gfx950 path has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(NF_ERR_ARG, "nf_create: device %d out of range (%d devices)", device, ndev);
@@ -236,14 +272,19 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     S->dim = S->nz > 1 ? 3 : (S->ny > 1 ? 2 : 1);               // src/FEM.cpp:33-35
     if ((if_lo || if_hi) && (S->dim != 3 || S->nz < 3)) { delete S; return fail(NF_ERR_ARG, "a slab needs a 3D mesh with at least 3 z-planes"); }
     S->N = (long)S->nx * S->ny * S->nz;
+    S->n1 = m + 1; S->nloc = 1; for (int t = 0; t < S->dim; ++t) S->nloc *= S->n1;
+    S->nphi = S->N * S->nloc; S->nb = std::min(k, m);
     S->hx.resize(S->nx); S->hy.assign(S->ny, 1.0); S->hz.assign(S->nz, 1.0);
     for (int i = 0; i < S->nx; ++i) S->hx[i] = xb[i + 1] - xb[i];
     if (S->dim >= 2) for (int i = 0; i < S->ny; ++i) S->hy[i] = yb[i + 1] - yb[i];
     if (S->dim == 3) for (int i = 0; i < S->nz; ++i) S->hz[i] = zb[i + 1] - zb[i];
-    S->nJx = (long)(S->nx + 1) * S->ny * S->nz;
-    S->nJy = S->dim >= 2 ? (long)S->nx * (S->ny + 1) * S->nz : 0;
-    S->nJz = S->dim == 3 ? (long)S->nx * S->ny * (S->nz + 1) : 0;
-    S->nJ = S->nJx + S->nJy + S->nJz;
+    {                                                            // src/FEM.cpp:177-259
+        int nf = 1, ni = k; for (int t = 1; t < S->dim; ++t) { nf *= k + 1; ni *= k + 1; }
+        S->nJx = (long)(S->nx + 1) * S->ny * S->nz * nf;
+        S->nJy = S->dim >= 2 ? (long)S->nx * (S->ny + 1) * S->nz * nf : 0;
+        S->nJz = S->dim == 3 ? (long)S->nx * S->ny * (S->nz + 1) * nf : 0;
+        S->nJ = S->nJx + S->nJy + S->nJz + S->N * S->dim * ni;
+    }
     S->nlines[0] = (long)S->ny * S->nz; S->nlines[1] = (long)S->nx * S->nz; S->nlines[2] = (long)S->nx * S->ny;
     nf_team *T = new nf_team();
     T->device = device; T->slabs.push_back(S); S->team = T; S->slab_index = 0;
@@ -258,14 +299,14 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     };
     if (hipStreamCreateWithFlags(&T->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(NF_ERR_HIP, "hipStreamCreate failed");
     up(&S->d_hx, S->hx); up(&S->d_hy, S->hy); up(&S->d_hz, S->hz); up(&S->d_xb, S->xb); up(&S->d_yb, S->yb); up(&S->d_zb, S->zb);
-    const size_t NN = (size_t)S->N * ng;
+    const size_t NN = (size_t)S->nphi * ng;
     if (rc == NF_OK) rc = dalloc(&S->d_phi, NN);
     if (rc == NF_OK) rc = dalloc(&S->d_raw, NN);
-    if (rc == NF_OK) rc = dalloc(&S->d_tf, S->N);
-    if (rc == NF_OK) rc = dalloc(&S->d_rhs, S->N);
-    if (rc == NF_OK) rc = dalloc(&S->d_r, S->N);
-    if (rc == NF_OK) rc = dalloc(&S->d_p, S->N);
-    if (rc == NF_OK) rc = dalloc(&S->d_q, S->N);
+    if (rc == NF_OK) rc = dalloc(&S->d_tf, S->nphi);
+    if (rc == NF_OK) rc = dalloc(&S->d_rhs, S->nphi);
+    if (rc == NF_OK) rc = dalloc(&S->d_r, S->nphi);
+    if (rc == NF_OK) rc = dalloc(&S->d_p, S->nphi);
+    if (rc == NF_OK) rc = dalloc(&S->d_q, S->nphi);
     if (rc == NF_OK && (if_lo || if_hi)) {
         const size_t nl = (size_t)S->nlines[2];
         double **arrs[] = { &S->d_clo, &S->d_chi, &S->d_rlo, &S->d_rhi, &S->d_ulo, &S->d_uhi };
@@ -365,7 +406,7 @@ long nf_info(nf_handle S, const char *key)
     nf_team *T = S->team;
 #define K(s, v) if (!strcmp(key, s)) return (long)(v)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
-    K("n_phi", S->N); K("n_J", S->nJ); K("n_loc", 1); K("last_outer", T->last_outer);
+    K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
     K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
 #undef K
@@ -410,10 +451,16 @@ int nf_build(nf_handle S)
     if (!S->xs_uploaded) return fail(NF_ERR_STATE, "nf_build: call nf_upload_xs first");
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
-    const int ng = S->ng; const long N = S->N; const size_t NN = (size_t)N * ng;
-    NFCHK(dalloc(&S->d_Cd, NN)); NFCHK(dalloc(&S->d_Mf, NN));
+    const int ng = S->ng; const long N = S->N, NP = S->nphi; const size_t NN = (size_t)N * ng;
+    NFCHK(dalloc(&S->d_Cd, (size_t)NP * ng)); NFCHK(dalloc(&S->d_Mf, (size_t)NP * ng));
     for (int d = 0; d < S->dim; ++d) {
         NFCHK(dalloc(&S->d_L[d], NN)); NFCHK(dalloc(&S->d_DR[d], NN)); NFCHK(dalloc(&S->d_D0[d], (size_t)S->nlines[d] * ng));
+    }
+    ChatArgs ch; ch.nloc = S->nloc;                               // C-hat_pp = prod 2/(2 i_t + 1), Legendre mass (include/FEM.hpp:197-200)
+    for (int p = 0; p < S->nloc; ++p) {
+        int q = p; double c = 1.0;
+        for (int t = 0; t < S->dim; ++t) { c *= 2.0 / (2.0 * (q % S->n1) + 1.0); q /= S->n1; }
+        ch.c[p] = c;
     }
     const bool slab = S->if_lo || S->if_hi;
     if (slab) {
@@ -424,13 +471,13 @@ int nf_build(nf_handle S)
     Geom G = make_geom(S);
     const int gN = grid_for(N, 256, 65535);
     for (int g = 0; g < ng; ++g) {
-        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigR + g * N, S->d_Cd + g * N, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 0);
-        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_NSF + g * N, S->d_Mf + g * N, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1);
+        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigR + g * N, S->d_Cd + g * NP, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 0, S->dim, ch);
+        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_NSF + g * N, S->d_Mf + g * NP, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1, S->dim, ch);
         for (int gp = 0; gp < ng; ++gp) {
             const int i = g * ng + gp;
             if (!S->d_SigS[i]) { dfree(S->d_Ms[i]); continue; }
-            NFCHK(dalloc(&S->d_Ms[i], N));
-            hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigS[i], S->d_Ms[i], S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1);
+            NFCHK(dalloc(&S->d_Ms[i], NP));
+            hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigS[i], S->d_Ms[i], S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1, S->dim, ch);
         }
         for (int d = 0; d < S->dim; ++d) {
             const long nl = S->nlines[d];
@@ -560,22 +607,19 @@ static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int
 }
 
 // ---- Schur apply -----------------------------------------------------------------------------
-template <int K, int NCH>
-static void launch_x_t(nf_solver *S, int g, const double *x, double *y, int lpl_log2, int first, int last,
+template <int NCH, int NB>
+static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int lpl_log2, int first, int last,
                        double *partials, const CgScalars *cg, unsigned grid)
 {
-    const long N = S->N; const double beta = (double)(1 << (S->dim - 1));
+    const long N = S->N;
     const bool vec = (S->nx % 2 == 0);
     hipStream_t st = S->team->stream;
-    if (vec)
-        hipLaunchKernelGGL((k_schur_x<K, NCH, true>), dim3(grid), dim3(256), 0, st, x, y, S->d_L[0] + g * N, S->d_DR[0] + g * N,
-                           S->d_D0[0] + g * S->nlines[0], S->d_Cd + g * N, S->nx, S->nlines[0], lpl_log2, beta, first, last, partials, cg);
-    else
-        hipLaunchKernelGGL((k_schur_x<K, NCH, false>), dim3(grid), dim3(256), 0, st, x, y, S->d_L[0] + g * N, S->d_DR[0] + g * N,
-                           S->d_D0[0] + g * S->nlines[0], S->d_Cd + g * N, S->nx, S->nlines[0], lpl_log2, beta, first, last, partials, cg);
+    const double *L = S->d_L[0] + g * N, *DR = S->d_DR[0] + g * N, *D0 = S->d_D0[0] + g * S->nlines[0];
+    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg);
+    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg);
 }
-
-static int launch_x(nf_solver *S, int g, const double *x, double *y, int last, double *partials, const CgScalars *cg, int *nparts)
+template <int NB>
+static int launch_x_nb(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts)
 {
     const int K = 2;
     int lanes = (S->nx + K - 1) / K, lpl_log2 = 0;
@@ -584,64 +628,62 @@ static int launch_x(nf_solver *S, int g, const double *x, double *y, int last, d
     const int nch = (S->nx + LPL * K - 1) / (LPL * K);
     const unsigned grid = (unsigned)((S->nlines[0] + 4 * LPW - 1) / (4 * LPW));
     if (nparts) *nparts = (int)grid;
-    if (nch <= 1) launch_x_t<2, 1>(S, g, x, y, lpl_log2, 1, last, partials, cg, grid);
-    else if (nch <= 2) launch_x_t<2, 2>(S, g, x, y, lpl_log2, 1, last, partials, cg, grid);
-    else if (nch <= 4) launch_x_t<2, 4>(S, g, x, y, lpl_log2, 1, last, partials, cg, grid);
-    else if (nch <= 8) launch_x_t<2, 8>(S, g, x, y, lpl_log2, 1, last, partials, cg, grid);
-    else return fail(NF_ERR_UNSUPPORTED, "nx = %d exceeds the x-line kernel limit (1024 cells)", S->nx);
+    if (nch <= 1) launch_x_t<1, NB>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
+    else if (nch <= 2) launch_x_t<2, NB>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
+    else if (nch <= 4) launch_x_t<4, NB>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
+    else if (nch <= 8 && NB == 0) launch_x_t<8, 0>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
+    else return fail(NF_ERR_UNSUPPORTED, "nx = %d exceeds the x-line kernel limit (%d cells)", S->nx, NB == 0 ? 1024 : 512);
     return NF_OK;
+}
+static int launch_x(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts)
+{
+    if (S->nb == 0) return launch_x_nb<0>(S, g, ma, G, last, partials, cg, nparts);
+    if (S->nb == 1) return launch_x_nb<1>(S, g, ma, G, last, partials, cg, nparts);
+    return launch_x_nb<2>(S, g, ma, G, last, partials, cg, nparts);
 }
 
 // zmode: 0 = plain line kernel (y lines, or z lines of an undivided mesh); 1 / 2 = slab chain passes (z lines)
-static int launch_s(nf_solver *S, int d, int g, const double *x, double *y, int last, double *partials, const CgScalars *cg, int *nparts, int zmode)
+static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts, int zmode)
 {
     nf_team *T = S->team;
-    const long N = S->N; const double beta = (double)(1 << (S->dim - 1));
+    const long N = S->N;
     const int n = d == 1 ? S->ny : S->nz;
     const long nxy = (long)S->nx * S->ny;
     const long sl = d == 1 ? S->nx : nxy, ostride = d == 1 ? nxy : S->nx;
     const int nouter = d == 1 ? S->nz : S->ny;
-    const bool pair = zmode == 0 && T->opt_s_pair && (S->nx % 2 == 0);   // two columns per thread, double2 accesses
-    int SEG = T->opt_s_seg ? T->opt_s_seg : (pair ? (n <= 256 ? 4 : 8) : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
+    int SEG = T->opt_s_seg ? T->opt_s_seg : (S->nb > 0 ? (n <= 256 ? 4 : 8) : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
     int NSEG = (n + SEG - 1) / SEG;
     if (NSEG > 128) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit", n);
-    const int cols = pair ? (S->nx + 1) / 2 : S->nx;              // thread columns needed
     int TX = T->opt_s_tx ? T->opt_s_tx : 64;
     while (TX > 8 && TX * NSEG > 1024) TX >>= 1;
     if (TX * NSEG > 1024) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than 1024 threads per block", n);
-    while (TX > 8 && TX / 2 >= cols) TX >>= 1;                    // narrow meshes
-    dim3 grid((unsigned)((cols + TX - 1) / TX), (unsigned)nouter), block((unsigned)(TX * NSEG));
+    while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;                   // narrow meshes
+    dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter), block((unsigned)(TX * NSEG));
     if (nparts) *nparts = (int)(grid.x * grid.y);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
-    if (pair) {
-        const size_t lds = (size_t)(4 * TX * NSEG + TX) * sizeof(double2) + 16 * sizeof(double);
-#define NF_LAUNCH_S2(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s2<SEGV, DIRV>), grid, block, lds, st, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg)
-        if (d == 1) { if (SEG == 4) NF_LAUNCH_S2(4, 1); else if (SEG == 8) NF_LAUNCH_S2(8, 1); else if (SEG == 16) NF_LAUNCH_S2(16, 1); else return fail(NF_ERR_ARG, "bad s_seg"); }
-        else        { if (SEG == 4) NF_LAUNCH_S2(4, 2); else if (SEG == 8) NF_LAUNCH_S2(8, 2); else if (SEG == 16) NF_LAUNCH_S2(16, 2); else return fail(NF_ERR_ARG, "bad s_seg"); }
-#undef NF_LAUNCH_S2
-        return NF_OK;
-    }
     const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
-    if (zmode == 0) {
-#define NF_LAUNCH_S(SEGV, DIRV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, false>), grid, block, lds, st, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg, sa)
-        if (d == 1) { if (SEG == 4) NF_LAUNCH_S(4, 1); else if (SEG == 8) NF_LAUNCH_S(8, 1); else if (SEG == 16) NF_LAUNCH_S(16, 1); else if (SEG == 32) NF_LAUNCH_S(32, 1); else return fail(NF_ERR_ARG, "bad s_seg"); }
-        else        { if (SEG == 4) NF_LAUNCH_S(4, 2); else if (SEG == 8) NF_LAUNCH_S(8, 2); else if (SEG == 16) NF_LAUNCH_S(16, 2); else if (SEG == 32) NF_LAUNCH_S(32, 2); else return fail(NF_ERR_ARG, "bad s_seg"); }
-#undef NF_LAUNCH_S
-        return NF_OK;
+#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa)
+#define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
+        else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
+    if (zmode != 0) {
+        const long nl = S->nlines[2];
+        sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
+        sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
+        NF_S_SEG(2, true, 0);
+    } else if (d == 1) {
+        if (S->nb == 0) NF_S_SEG(1, false, 0); else if (S->nb == 1) NF_S_SEG(1, false, 1); else NF_S_SEG(1, false, 2);
+    } else {
+        if (S->nb == 0) NF_S_SEG(2, false, 0); else if (S->nb == 1) NF_S_SEG(2, false, 1); else NF_S_SEG(2, false, 2);
     }
-    const long nl = S->nlines[2];
-    sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
-    sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
-#define NF_LAUNCH_SS(SEGV) hipLaunchKernelGGL((k_schur_s<SEGV, 2, true>), grid, block, lds, st, x, y, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, beta, last, partials, cg, sa)
-    if (SEG == 4) NF_LAUNCH_SS(4); else if (SEG == 8) NF_LAUNCH_SS(8); else if (SEG == 16) NF_LAUNCH_SS(16); else if (SEG == 32) NF_LAUNCH_SS(32); else return fail(NF_ERR_ARG, "bad s_seg");
-#undef NF_LAUNCH_SS
+#undef NF_S_SEG
+#undef NF_S
     return NF_OK;
 }
 
-// y = S_g x on every local slab.  xs / ys: per-slab device pointers.  With `want_dot` the last pass leaves the block
-// partials of x.y in the team buffer and counts[] receives the number per slab.
+// y = S_g x on every local slab.  xs / ys: per-slab device pointers (nphi doubles, layout [p][e]).  With `want_dot` the
+// passes of the last direction leave the block partials of x.y in the team buffer and counts[] receives the number per slab.
 static int team_schur_apply(nf_team *T, int g, const std::vector<const double *> &xs, const std::vector<double *> &ys, bool want_dot,
                             const CgScalars *cg, std::vector<int> *counts)
 {
@@ -652,7 +694,11 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
     if (T->profile) prof_begin(T, 3, &ta, &tb);
     if (any_if) {                                                 // partition method step 1 + interface exchange
         if (T->profile) prof_begin(T, 4, &a, &b);
-        for (int i = 0; i < ns; ++i) { nf_solver *S = T->slabs[i]; if (S->if_lo || S->if_hi) NFCHK(launch_s(S, 2, g, xs[i], ys[i], 0, nullptr, cg, nullptr, 1)); }
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            if (!(S->if_lo || S->if_hi)) continue;
+            NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, cg, nullptr, 1));
+        }
         if (T->profile) (void)hipEventRecord(b, T->stream);
         NFCHK(exchange_planes(T, 0, 0));
     }
@@ -661,16 +707,22 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
         if (T->profile) prof_begin(T, d, &a, &b);
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
-            double *part = (want_dot && last) ? T->d_partials + i * T->slab_cap : nullptr;
-            int np = 0;
-            if (d == 0) NFCHK(launch_x(S, g, xs[i], ys[i], last, part, cg, &np));
-            else if (d == 2 && (S->if_lo || S->if_hi)) {
-                const long nl = S->nlines[2];
-                hipLaunchKernelGGL(k_separators, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, T->stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi,
-                                   S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg);
-                NFCHK(launch_s(S, 2, g, xs[i], ys[i], last, part, cg, &np, 2));
-            } else NFCHK(launch_s(S, d, g, xs[i], ys[i], last, part, cg, &np, 0));
-            if (counts && last) (*counts)[i] = np;
+            const Geom G = make_geom(S);
+            int total = 0;
+            for (int mode = 0; mode < n_modes(S); ++mode) {
+                double *part = (want_dot && last) ? T->d_partials + i * T->slab_cap + total : nullptr;
+                const ModeArgs ma = mode_args(S, g, d, mode, xs[i], ys[i]);
+                int np = 0;
+                if (d == 0) NFCHK(launch_x(S, g, ma, G, last, part, cg, &np));
+                else if (d == 2 && (S->if_lo || S->if_hi)) {
+                    const long nl = S->nlines[2];
+                    hipLaunchKernelGGL(k_separators, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, T->stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi,
+                                       S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg);
+                    NFCHK(launch_s(S, 2, g, ma, G, last, part, cg, &np, 2));
+                } else NFCHK(launch_s(S, d, g, ma, G, last, part, cg, &np, 0));
+                total += np;
+            }
+            if (counts && last) (*counts)[i] = total;
         }
         if (T->profile) (void)hipEventRecord(b, T->stream);
     }
@@ -719,8 +771,8 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     std::vector<const double *> ps(ns); std::vector<double *> qs(ns);
     for (int i = 0; i < ns; ++i) {
         nf_solver *S = T->slabs[i];
-        gcnt[i] = grid_for(S->N); ps[i] = S->d_p; qs[i] = S->d_q;
-        hipLaunchKernelGGL(k_cg_init, dim3(gcnt[i]), dim3(256), 0, T->stream, rhs[i], x[i], S->d_r, S->d_p, S->N, T->d_partials + i * T->slab_cap);
+        gcnt[i] = grid_for(S->nphi); ps[i] = S->d_p; qs[i] = S->d_q;
+        hipLaunchKernelGGL(k_cg_init, dim3(gcnt[i]), dim3(256), 0, T->stream, rhs[i], x[i], S->d_r, S->d_p, S->nphi, T->d_partials + i * T->slab_cap);
     }
     NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
     CgScalars sc; memset(&sc, 0, sizeof sc);
@@ -733,12 +785,12 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             NFCHK(team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0));
             for (int i = 0; i < ns; ++i) {
                 nf_solver *S = T->slabs[i];
-                hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->N, T->d_cg, T->d_partials + i * T->slab_cap);
+                hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
             }
             NFCHK(team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0));
             for (int i = 0; i < ns; ++i) {
                 nf_solver *S = T->slabs[i];
-                hipLaunchKernelGGL(k_cg_pupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_p, S->d_r, S->N, T->d_cg);
+                hipLaunchKernelGGL(k_cg_pupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_p, S->d_r, S->nphi, T->d_cg);
             }
         }
         launched += nb;
@@ -775,6 +827,7 @@ int nf_build_diagonal_cache(nf_handle S)
     if (!S) return fail(NF_ERR_ARG, "null handle");
     if (!S->built) return fail(NF_ERR_STATE, "nf_build_diagonal_cache: call nf_build first");
     if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh");
+    if (S->k != 0 || S->m != 0) return NF_OK;                     // "non applicable (ordre > 0)", src/NeutFEM.cpp:484-487
     if (S->diag_valid) return NF_OK;
     HIPCHK(hipSetDevice(S->device));
     const long N = S->N;
@@ -791,32 +844,51 @@ int nf_get_diagonal_cache(nf_handle S, int g, double *sinv_host)
 {
     if (!S || g < 0 || g >= S->ng || !sinv_host) return fail(NF_ERR_ARG, "nf_get_diagonal_cache: bad arguments");
     NFCHK(nf_build_diagonal_cache(S));
+    if (!S->diag_valid) return fail(NF_ERR_UNSUPPORTED, "the diagonal cache exists for RT0-P0 only");
     HIPCHK(hipMemcpy(sinv_host, S->d_Sinv + g * S->N, S->N * sizeof(double), hipMemcpyDeviceToHost));
     return NF_OK;
 }
 
 // ---- state -------------------------------------------------------------------------------------
+// host layout [g][e*nloc + p] (reference, src/FEM.cpp:321-334) <-> device layout [g][p][e]
+static int phi_transfer(nf_solver *S, double *host, bool to_device)
+{
+    HIPCHK(hipSetDevice(S->device));
+    hipStream_t st = S->team->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    const size_t NN = (size_t)S->nphi * S->ng;
+    if (S->nloc == 1) {
+        if (to_device) HIPCHK(hipMemcpy(S->d_phi, host, NN * sizeof(double), hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy(host, S->d_phi, NN * sizeof(double), hipMemcpyDeviceToHost));
+        return NF_OK;
+    }
+    double *tmp = nullptr; NFCHK(dalloc(&tmp, NN));
+    if (to_device) HIPCHK(hipMemcpy(tmp, host, NN * sizeof(double), hipMemcpyHostToDevice));
+    for (int g = 0; g < S->ng; ++g) {
+        const double *src = (to_device ? tmp : S->d_phi) + (size_t)g * S->nphi;
+        double *dst = (to_device ? S->d_phi : tmp) + (size_t)g * S->nphi;
+        hipLaunchKernelGGL(k_transpose_dofs, dim3(grid_for(S->nphi)), dim3(256), 0, st, src, dst, S->N, S->nloc, to_device ? 1 : 0);
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (!to_device) HIPCHK(hipMemcpy(host, tmp, NN * sizeof(double), hipMemcpyDeviceToHost));
+    dfree(tmp);
+    return NF_OK;
+}
 int nf_set_phi(nf_handle S, const double *phi)
 {
     if (!S || !phi) return fail(NF_ERR_ARG, "nf_set_phi: bad arguments");
-    HIPCHK(hipSetDevice(S->device));
-    HIPCHK(hipStreamSynchronize(S->team->stream));
-    HIPCHK(hipMemcpy(S->d_phi, phi, (size_t)S->N * S->ng * sizeof(double), hipMemcpyHostToDevice));
-    return NF_OK;
+    return phi_transfer(S, const_cast<double *>(phi), true);
 }
 int nf_get_phi(nf_handle S, double *phi)
 {
     if (!S || !phi) return fail(NF_ERR_ARG, "nf_get_phi: bad arguments");
-    HIPCHK(hipSetDevice(S->device));
-    HIPCHK(hipStreamSynchronize(S->team->stream));
-    HIPCHK(hipMemcpy(phi, S->d_phi, (size_t)S->N * S->ng * sizeof(double), hipMemcpyDeviceToHost));
-    return NF_OK;
+    return phi_transfer(S, phi, false);
 }
 int nf_reset_flux(nf_handle S)
 {
     if (!S) return fail(NF_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(S->device));
-    std::vector<double> ones((size_t)S->N * S->ng, 1.0);        // Sol_Phi_ = 1, src/NeutFEM.cpp:347-354
+    std::vector<double> ones((size_t)S->nphi * S->ng, 1.0);     // Sol_Phi_ = 1 on every DOF, src/NeutFEM.cpp:347-354
     HIPCHK(hipMemcpy(S->d_phi, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
     S->team->has_valid_keff = 0; S->raw_valid = false;
     return NF_OK;
@@ -828,6 +900,7 @@ int nf_get_J(nf_handle S, double *J_host)
 {
     if (!S || !J_host) return fail(NF_ERR_ARG, "nf_get_J: bad arguments");
     if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "nf_get_J is not available on a slab (currents are reconstructed on undivided meshes only)");
+    if (S->k != 0) return fail(NF_ERR_UNSUPPORTED, "nf_get_J is implemented for RT0 only (RT%d asked)", S->k);
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const long N = S->N, nJ = S->nJ;
@@ -895,7 +968,8 @@ static int coarse_init(nf_solver *S, const nf_keff_opts *o, double *k_coarse, do
     }
     if (rc == NF_OK) {
         T->coarse_outer = nout;
-        hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, C->team->stream, C->d_phi, d_dst, S->nx, S->ny, S->nz, rx, ry, rz, ng);
+        (void)hipMemsetAsync(d_dst, 0, (size_t)S->nphi * ng * sizeof(double), C->team->stream);   // higher moments 0 (:2585-2606)
+        hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, C->team->stream, C->d_phi, d_dst, S->nx, S->ny, S->nz, rx, ry, rz, ng, S->nphi);
         if (hipStreamSynchronize(C->team->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
     }
     std::string keep = g_err;
@@ -911,11 +985,13 @@ int nf_solve_coarse(nf_handle S, const nf_keff_opts *o, double *k_coarse, double
     if (!S->built) return fail(NF_ERR_STATE, "nf_solve_coarse: call nf_build first");
     if (!team_is_single(S->team)) return fail(NF_ERR_UNSUPPORTED, "coarse-mesh initialisation is not available on a slab-decomposed mesh");
     HIPCHK(hipSetDevice(S->device));
-    const size_t NN = (size_t)S->N * S->ng;
     bool done = false; double kc = 1.0;
     if (o->n_coarse_factors > 0) NFCHK(coarse_init(S, o, &kc, S->d_raw, &done));
     S->raw_valid = false;
-    HIPCHK(hipMemcpy(phi_host, done ? S->d_raw : S->d_phi, NN * sizeof(double), hipMemcpyDeviceToHost));
+    if (done) std::swap(S->d_raw, S->d_phi);                     // reuse the layout-converting download
+    int rc = phi_transfer(S, phi_host, false);
+    if (done) std::swap(S->d_raw, S->d_phi);
+    NFCHK(rc);
     *k_coarse = done ? kc : 1.0;
     return NF_OK;
 }
@@ -928,7 +1004,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     const int ng = S0->ng;
     const bool single = team_is_single(T);
     NFCHK(team_prepare(T));
-    int use_diag = o->use_diagonal_solver ? 1 : 0;                // RT0-P0 only exists here
+    int use_diag = (o->use_diagonal_solver && S0->k == 0 && S0->m == 0) ? 1 : 0;   // flag dropped for order > 0 (:1640-1644)
     if (use_diag) { if (!single) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh"); NFCHK(nf_build_diagonal_cache(S0)); }
     double keff = T->has_valid_keff ? T->last_keff : 1.0;        // :1662
     T->coarse_outer = 0;
@@ -938,7 +1014,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         NFCHK(coarse_init(S0, o, &kc, S0->d_phi, &done));
         keff = done ? kc : 1.0;
     }
-    long Ntot = 0; for (auto *S : T->slabs) Ntot += S->N;
+    long Ntot = 0; for (auto *S : T->slabs) Ntot += S->nphi;
     // SchurSolver type: DIRECT_* or n_phi < 200 -> "exact" solve (CG to 1e-14 stands in)
     const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (single && Ntot < 200);
     const double cg_tol = direct ? 1e-14 : o->tol_flux;           // SetTolerance forwards tol_flux (:334)
@@ -956,22 +1032,22 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     double hout[4];
     std::vector<int> gN(ns), gT(ns);
     std::vector<const double *> rhs(ns); std::vector<double *> sol(ns);
-    for (int i = 0; i < ns; ++i) { gN[i] = grid_for(T->slabs[i]->N); gT[i] = grid_for(T->slabs[i]->N * ng); }
+    for (int i = 0; i < ns; ++i) { gN[i] = grid_for(T->slabs[i]->nphi); gT[i] = grid_for(T->slabs[i]->nphi * ng); }
     for (int it = 0; it < o->max_outer; ++it) {
         // total_fiss and prod_old (:1700-1707)
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
-            hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_phi, ng, S->N, S->d_tf, T->d_partials + i * T->slab_cap);
+            hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_phi, ng, S->nphi, S->d_tf, T->d_partials + i * T->slab_cap);
         }
         NFCHK(team_finalize(T, FIN_SUM, gN, 1, T->d_out, 0.0, 0));
         for (int g = 0; g < ng; ++g) {
             for (int i = 0; i < ns; ++i) {
-                nf_solver *S = T->slabs[i]; const long N = S->N;
+                nf_solver *S = T->slabs[i]; const long N = S->N, NP = S->nphi;
                 for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[g * ng + gp] : nullptr;
-                double *dst = use_diag ? S->d_raw + g * N : S->d_rhs;
+                double *dst = use_diag ? S->d_raw + g * NP : S->d_rhs;
                 hipLaunchKernelGGL(k_group_rhs, dim3(gN[i]), dim3(256), 0, T->stream, sa, g, S->d_Chi + g * N, S->d_tf, 1.0 / keff, S->d_raw, S->d_phi,
-                                   use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, N);
-                rhs[i] = S->d_rhs; sol[i] = S->d_raw + g * N;
+                                   use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, NP, N);
+                rhs[i] = S->d_rhs; sol[i] = S->d_raw + g * NP;
             }
             int its = 0;
             if (!use_diag) NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr));
@@ -980,7 +1056,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         // prod_new, norms (:1766-1779)
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
-            hipLaunchKernelGGL(k_outer_reduce, dim3(gT[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_raw, S->d_phi, S->N * ng, T->d_partials + i * T->slab_cap, T->partial_stride);
+            hipLaunchKernelGGL(k_outer_reduce, dim3(gT[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_raw, S->d_phi, S->nphi * ng, T->d_partials + i * T->slab_cap, T->partial_stride);
         }
         NFCHK(team_finalize(T, FIN_SUM, gT, 3, T->d_out + 1, 0.0, 0));
         HIPCHK(hipMemcpyAsync(hout, T->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, T->stream));
@@ -1001,7 +1077,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             else { mode = 3; a = (4. / sigma) * ca[cheb_it]; b = cbv[cheb_it]; }
         }
         for (int i = 0; i < ns; ++i) {
-            nf_solver *S = T->slabs[i]; const long NT = S->N * ng;
+            nf_solver *S = T->slabs[i]; const long NT = S->nphi * ng;
             if (mode && !S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NT)); NFCHK(dalloc(&S->d_p1, (size_t)NT)); }
             hipLaunchKernelGGL(k_normalize_cheb, dim3(gT[i]), dim3(256), 0, T->stream, S->d_raw, S->d_phi, S->d_p0, S->d_p1, NT, norm,
                                norm > 1e-14 ? 1 : 0, mode, a, b);
@@ -1064,7 +1140,7 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
     NFCHK(team_prepare(T));
     std::vector<const double *> xs; std::vector<double *> ys;
     for (auto *X : T->slabs) {
-        hipLaunchKernelGGL(k_fill_pattern, dim3(grid_for(X->N)), dim3(256), 0, T->stream, X->d_p, X->N);
+        hipLaunchKernelGGL(k_fill_pattern, dim3(grid_for(X->nphi)), dim3(256), 0, T->stream, X->d_p, X->nphi);
         xs.push_back(X->d_p); ys.push_back(X->d_q);
     }
     NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));   // warm-up
@@ -1089,7 +1165,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     nf_team *T = S->team;
     if (!strcmp(key, "s_tx")) T->opt_s_tx = (int)value;
     else if (!strcmp(key, "s_seg")) T->opt_s_seg = (int)value;
-    else if (!strcmp(key, "s_pair")) T->opt_s_pair = (int)value;
+    else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;

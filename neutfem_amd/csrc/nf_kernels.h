@@ -108,27 +108,55 @@ __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgSca
 }
 
 // ---------------------------------------------------------------------------------------------
-// BuildMatrices, per-cell part (src/NeutFEM.cpp:1163-1302): C diag, fission and scatter diagonals.
-// P0: C_ee = SigR*detJ*C-hat = SigR*V ; M_fiss = nsf*V ; entries <= 1e-14 dropped.
+// BuildMatrices, per-DOF diagonals (src/NeutFEM.cpp:1163-1302): C, fission and scatter matrices are diagonal
+// (Legendre orthogonality): value = xs * detJ * C-hat_pp, C-hat_pp = prod_axes 2/(2 i_t + 1).  Output is SoA [p][e].
+// mode 0 (C): entries <= 1e-14 dropped.  mode 1 (fission / scatter): P0: kept iff |xs| > 1e-14 (value xs*V);
+// P>=1: element skipped iff |xs| < 1e-14, entries <= 1e-14 dropped (:1204-1302).
+struct ChatArgs { int nloc; double c[27]; };
 __global__ void k_cell_coef(const double *__restrict__ xs, double *__restrict__ out, const double *__restrict__ hx,
                             const double *__restrict__ hy, const double *__restrict__ hz, int nx, int ny, long N,
-                            int mode /*0: threshold on product (C), 1: threshold on xs (fission/scatter)*/)
+                            int mode, int dim, ChatArgs ch)
 {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
         const int ix = (int)(e % nx); const long r = e / nx; const int iy = (int)(r % ny); const int iz = (int)(r / ny);
-        const double V = hx[ix] * hy[iy] * hz[iz];
         const double s = xs[e];
-        double v = s * V;
-        if (mode == 0) { if (!(fabs(v) > 1e-14)) v = 0.0; }
-        else { if (!(fabs(s) > 1e-14)) v = 0.0; }
-        out[e] = v;
+        if (ch.nloc == 1) {
+            const double V = hx[ix] * hy[iy] * hz[iz];
+            double v = s * V;
+            if (mode == 0) { if (!(fabs(v) > 1e-14)) v = 0.0; }
+            else { if (!(fabs(s) > 1e-14)) v = 0.0; }
+            out[e] = v;
+        } else {
+            double detJ = hx[ix] / 2.0;
+            if (dim >= 2) detJ *= hy[iy] / 2.0;
+            if (dim == 3) detJ *= hz[iz] / 2.0;
+            const bool skip = mode == 1 && fabs(s) < 1e-14;
+            for (int p = 0; p < ch.nloc; ++p) {
+                double v = skip ? 0.0 : s * detJ * ch.c[p];
+                if (!(fabs(v) > 1e-14)) v = 0.0;
+                out[(long)p * N + e] = v;
+            }
+        }
+    }
+}
+// host layout [e*nloc + p] <-> device layout [p*N + e]
+__global__ void k_transpose_dofs(const double *__restrict__ in, double *__restrict__ out, long N, int nloc, int to_soa)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < N * nloc; i += gridDim.x * 256L) {
+        const long e = to_soa ? i % N : i / nloc; const int p = to_soa ? (int)(i / N) : (int)(i % nloc);
+        if (to_soa) out[i] = in[e * nloc + p]; else out[i] = in[(long)p * N + e];
     }
 }
 
 struct Geom {
-    int dim, nx, ny, nz;
+    int dim, nx, ny, nz, k;
     const double *hx, *hy, *hz;
-    double cLL, cLR, beta;       // RT0 unit tables: A-hat = 2^(dim-1) [[2/3,1/3],[1/3,2/3]], B-hat = -+2^(dim-1)
+    // Line operators are stored for UNIT transverse scaling: for transverse Legendre mode a the whole chain matrix
+    // (Dirichlet term included, src/NeutFEM.cpp:1458-1489) is T_a times the unit one, T_a = prod 2/(2 a_t + 1), so
+    // the LDL^T multipliers are common to all modes and u = T^-1 t does not depend on T_a at all.
+    // aLL/aLR: 1-D face block after the k bubbles of the cell have been condensed (RT0: [[2/3,1/3],[1/3,2/3]],
+    // RT1: [[1/4,-1/12],..], RT2: [[2/15,1/30],..]); T0 = 2^(dim-1) is the mode-0 scaling (B-hat = -+T0 for RT0).
+    double aLL, aLR, T0;
     int dir_lo[3], dir_hi[3];    // Dirichlet flags per direction (src/NeutFEM.cpp:2338-2347 attribute map)
 };
 
@@ -142,19 +170,39 @@ __device__ __forceinline__ double geom_factor(const Geom &G, int d, int ix, int 
     if (d == 1) return 2.0 * hy / (hx * hz);
     return 2.0 * hz / (hx * hy);
 }
-// Dirichlet diagonal term I_f * 2 * D (src/NeutFEM.cpp:1350, 1458-1489)
+// Dirichlet diagonal term I_f(a) * 2 * D / T_a (src/NeutFEM.cpp:1350, 1458-1489): 2D, 4D/area, 8D/area
 __device__ __forceinline__ double dirichlet_term(const Geom &G, int d, int ix, int iy, int iz, double D)
 {
     double area = d == 0 ? G.hy[iy] * G.hz[iz] : d == 1 ? G.hx[ix] * G.hz[iz] : G.hx[ix] * G.hy[iy];
-    double I = G.dim == 1 ? 1.0 : G.dim == 2 ? 2.0 * 2.0 / area : 4.0 * 2.0 * 2.0 / area;
+    double I = G.dim == 1 ? 1.0 : G.dim == 2 ? 2.0 / area : 4.0 / area;
     return I * 2.0 * D;
 }
 __device__ __forceinline__ void cell_a(const Geom &G, int d, int ix, int iy, int iz, double D, double &a2, double &a1)
 {
     const double a = (1.0 / D) * geom_factor(G, d, ix, iy, iz);
-    a2 = G.cLL * a; if (!(fabs(a2) > 1e-14)) a2 = 0.0;      // src/NeutFEM.cpp:1064 drop threshold
-    a1 = G.cLR * a; if (!(fabs(a1) > 1e-14)) a1 = 0.0;
+    a2 = G.aLL * a; a1 = G.aLR * a;
+    if (G.k == 0) {                                             // src/NeutFEM.cpp:1064 drop threshold on the real entries
+        if (!(fabs(G.T0 * a2) > 1e-14)) a2 = 0.0;
+        if (!(fabs(G.T0 * a1) > 1e-14)) a1 = 0.0;
+    }
 }
+
+// One (direction, transverse mode) pass of the Schur apply for RT_k-P_m.  The phi moments (i along the line,
+// transverse index a) of a cell couple to the line unknowns of mode a only:
+//   faces    t_f = xR_{f-1} - xL_f,   xR = x_0 - sum_l eR_l G_l x_{l+1},  xL = x_0 + sum_l eL_l G_l x_{l+1}
+//   solve    T_unit u = t             (bubbles condensed per cell: scalars because M^bb is diagonal for k <= 2)
+//   bubbles  v_l = G_l x_{l+1} iM_l / c_e - (eL_l u_c + eR_l u_{c+1}),  c_e = factor_dir / D
+//   output   y_0 += T_a (u_{c+1} - u_c),   y_{l+1} += T_a G_l v_l
+// NB = number of bubble moments that exist in P_m (min(k, m)); NB = 0 is RT0-P0 (or RT_k-P0).
+struct ModeArgs {
+    double Ta;
+    double eL[2], eR[2], Gc[2], iM[2];
+    const double *x[3];          // moment arrays of the input vector: x[0] (along-index 0), x[1], x[2]
+    double *y[3];
+    const double *Cd[3];         // C diagonal of the same moments (first pass only)
+    const double *D;             // diffusion coefficient per cell (for 1/c_e); used when NB > 0
+    int dir;
+};
 
 // AssembleA + ApplyDirichletToA + SparseLU (src/NeutFEM.cpp:1036-1076,1328-1456; src/solvers.cpp:163)
 // for one direction: one thread per grid line assembles the tridiagonal T of that line on the fly
@@ -252,7 +300,7 @@ __global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double 
     const int ix = (int)(e % G.nx); const long r = e / G.nx; const int iy = (int)(r % G.ny); const int iz = (int)(r / G.ny);
     const long nxy = (long)G.nx * G.ny;
     double S = Cd[e];
-    const double b2 = G.beta * G.beta;
+    const double b2 = G.T0;                                      // B^2 / A_ff = T0^2 / (T0 A_unit)
     for (int d = 0; d < G.dim; ++d) {
         const int c = d == 0 ? ix : d == 1 ? iy : iz;
         const int n = d == 0 ? G.nx : d == 1 ? G.ny : G.nz;
@@ -269,8 +317,8 @@ __global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double 
             int jx = ix + (d == 0), jy = iy + (d == 1), jz = iz + (d == 2);
             cell_a(G, d, jx, jy, jz, D[e + sl], b2n, b1n); Ahi += b2n;
         } else if (G.dir_hi[d]) Ahi += dirichlet_term(G, d, ix, iy, iz, D[e]);
-        if (fabs(Alo) > 1e-14) S += b2 / Alo;
-        if (fabs(Ahi) > 1e-14) S += b2 / Ahi;
+        if (fabs(G.T0 * Alo) > 1e-14) S += b2 / Alo;
+        if (fabs(G.T0 * Ahi) > 1e-14) S += b2 / Ahi;
     }
     Sinv[e] = fabs(S) > 1e-14 ? 1.0 / S : 0.0;
 }
@@ -278,15 +326,20 @@ __global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double 
 // ---------------------------------------------------------------------------------------------
 // Schur apply, x direction (unit stride along the line).  One wavefront scans 64/LPL lines;
 // a lane owns K consecutive cells per chunk of LPL*K cells, NCH chunks cover the line.
-//   y[c] = (first ? Cd[c]*x[c] : y[c]) + beta*(u[c+1]-u[c]),   T u = t,  t_f = beta*(x[f-1]-x[f])
-// Forward  z_{c+1} = t_{c+1} - L[c] z_c, w = z * dinv ; backward u_f = w_f - L[f] u_{f+1}.
-template <int K, int NCH, bool VEC>
-__global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, double *__restrict__ y,
-                                                 const double *__restrict__ L, const double *__restrict__ DR,
-                                                 const double *__restrict__ D0, const double *__restrict__ Cd,
-                                                 int nx, long nlines, int lpl_log2, double beta, int first, int last,
-                                                 double *__restrict__ partials, const CgScalars *__restrict__ cg)
+//   forward  z_{c+1} = t_{c+1} - L[c] z_c, w = z * dinv ; backward u_f = w_f - L[f] u_{f+1}   (ModeArgs: t, outputs)
+// `first`: y_p = Cd_p x_p + ... (the x pass is the first to touch every moment), else accumulate.
+__device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, double &a, double &b, bool ok2)
 {
+    if (vec) { double2 v = make_double2(0, 0); if (ok) v = *reinterpret_cast<const double2 *>(p + i); a = v.x; b = v.y; }
+    else { a = ok ? p[i] : 0.0; b = ok2 ? p[i + 1] : 0.0; }
+}
+template <int K, int NCH, bool VEC, int NB>
+__global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+                                                 const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
+                                                 int first, int last, double *__restrict__ partials,
+                                                 const CgScalars *__restrict__ cg)
+{
+    static_assert(K == 2, "two cells per lane and chunk");
     __shared__ double sred[4];
     if (cg && cg->done) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -295,46 +348,47 @@ __global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, d
     const long line = ((long)blockIdx.x * 4 + wave) * LPW + sub;
     const bool lv = line < nlines;
     const long base = lv ? line * nx : 0;
-    double xs[NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], yo[NCH][K];
+    const int iy = lv ? (int)(line % ny) : 0, iz = lv ? (int)(line / ny) : 0;
+    double xm[NB + 1][NCH][K], yo[NB + 1][NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], xL[NCH][K], xR[NCH][K], ic[NCH][K];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
-        if (VEC) {
-            static_assert(!VEC || K == 2, "vector path is K=2");
-            const bool ok = lv && c0 < nx;
-            double2 vx = make_double2(0, 0), vl = vx, vr = vx, vy = vx;
-            if (ok) {
-                vx = *reinterpret_cast<const double2 *>(x + base + c0);
-                vl = *reinterpret_cast<const double2 *>(L + base + c0);
-                vr = *reinterpret_cast<const double2 *>(DR + base + c0);
-                vy = first ? *reinterpret_cast<const double2 *>(Cd + base + c0) : *reinterpret_cast<const double2 *>(y + base + c0);
-            }
-            xs[ch][0] = vx.x; xs[ch][K - 1] = vx.y; Ls[ch][0] = vl.x; Ls[ch][K - 1] = vl.y;
-            Rs[ch][0] = vr.x; Rs[ch][K - 1] = vr.y; yo[ch][0] = vy.x; yo[ch][K - 1] = vy.y;
-        } else {
+        const bool ok = lv && c0 < nx, ok2 = lv && c0 + 1 < nx;
+        ld2(L, base + c0, ok, VEC, Ls[ch][0], Ls[ch][1], ok2);
+        ld2(DR, base + c0, ok, VEC, Rs[ch][0], Rs[ch][1], ok2);
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int c = c0 + j; const bool ok = lv && c < nx;
-                xs[ch][j] = ok ? x[base + c] : 0.0;
-                Ls[ch][j] = ok ? L[base + c] : 0.0;
-                Rs[ch][j] = ok ? DR[base + c] : 0.0;
-                yo[ch][j] = ok ? (first ? Cd[base + c] : y[base + c]) : 0.0;
+        for (int q = 0; q <= NB; ++q) {
+            ld2(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
+            ld2(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            double pl = 0.0, pr = 0.0;
+            ic[ch][j] = 0.0;
+            if (NB > 0) {
+                double dd0, dd1; ld2(ma.D, base + c0, ok, VEC, dd0, dd1, ok2);
+                const double dd = j == 0 ? dd0 : dd1;
+                const bool okj = j == 0 ? ok : ok2;
+                ic[ch][j] = okj ? dd / geom_factor(G, 0, c0 + j, iy, iz) : 0.0;      // 1 / c_e
+#pragma unroll
+                for (int l = 0; l < NB; ++l) { const double gx = ma.Gc[l] * xm[l + 1][ch][j]; pl += ma.eL[l] * gx; pr += ma.eR[l] * gx; }
             }
+            xL[ch][j] = xm[0][ch][j] + pl; xR[ch][j] = xm[0][ch][j] - pr;
         }
     }
     const double d0 = lv ? D0[line] : 0.0;
-    const double z0 = __shfl(-beta * xs[0][0], 0, LPL);
+    const double z0 = __shfl(-xL[0][0], 0, LPL);
     // ---- forward sweep over chunks
     double carry = z0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        double xn = __shfl_down(xs[ch][0], 1, LPL);
+        double xn = __shfl_down(xL[ch][0], 1, LPL);
         double xc = 0.0;
-        if (ch + 1 < NCH) xc = __shfl(xs[ch + 1 < NCH ? ch + 1 : ch][0], 0, LPL);
+        if (ch + 1 < NCH) xc = __shfl(xL[ch + 1 < NCH ? ch + 1 : ch][0], 0, LPL);
         if (li == LPL - 1) xn = xc;
         double t[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) t[j] = beta * (xs[ch][j] - (j + 1 < K ? xs[ch][j + 1 < K ? j + 1 : j] : xn));
+        for (int j = 0; j < K; ++j) t[j] = xR[ch][j] - (j + 1 < K ? xL[ch][j + 1 < K ? j + 1 : j] : xn);
         double A = 1.0, B = 0.0;
 #pragma unroll
         for (int j = 0; j < K; ++j) { B = t[j] - Ls[ch][j] * B; A = -Ls[ch][j] * A; }
@@ -376,20 +430,27 @@ __global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, d
         double wprev = 0.0;
         if (ch > 0) wprev = __shfl(w[ch > 0 ? ch - 1 : 0][K - 1], LPL - 1, LPL);
         if (li == 0) ulo = (ch == 0 ? z0 * d0 : wprev) - Ls[ch][0] * uv[0];
-        double yv[K];
+        double yv[NB + 1][K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const double lo = j == 0 ? ulo : uv[j > 0 ? j - 1 : 0];
-            const double add = beta * (uv[j] - lo);
-            yv[j] = (first ? yo[ch][j] * xs[ch][j] : yo[ch][j]) + add;
-            dot += xs[ch][j] * yv[j];           // padded cells have x = 0
+            yv[0][j] = (first ? yo[0][ch][j] * xm[0][ch][j] : yo[0][ch][j]) + ma.Ta * (uv[j] - lo);
+            dot += xm[0][ch][j] * yv[0][j];           // padded cells have x = 0
+#pragma unroll
+            for (int l = 0; l < NB; ++l) {
+                const double v = ma.Gc[l] * xm[l + 1][ch][j] * ma.iM[l] * ic[ch][j] - (ma.eL[l] * lo + ma.eR[l] * uv[j]);
+                yv[l + 1][j] = (first ? yo[l + 1][ch][j] * xm[l + 1][ch][j] : yo[l + 1][ch][j]) + ma.Ta * ma.Gc[l] * v;
+                dot += xm[l + 1][ch][j] * yv[l + 1][j];
+            }
         }
         const int c0 = (ch * LPL + li) * K;
-        if (VEC) {
-            if (lv && c0 < nx) *reinterpret_cast<double2 *>(y + base + c0) = make_double2(yv[0], yv[K - 1]);
-        } else {
 #pragma unroll
-            for (int j = 0; j < K; ++j) if (lv && c0 + j < nx) y[base + c0 + j] = yv[j];
+        for (int q = 0; q <= NB; ++q) {
+            if (VEC) { if (lv && c0 < nx) *reinterpret_cast<double2 *>(ma.y[q] + base + c0) = make_double2(yv[q][0], yv[q][K - 1]); }
+            else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) if (lv && c0 + j < nx) ma.y[q][base + c0 + j] = yv[q][j];
+            }
         }
     }
     if (last && partials) {
@@ -403,9 +464,9 @@ __global__ __launch_bounds__(256) void k_schur_x(const double *__restrict__ x, d
 // the segment held in registers; segment summaries (affine maps) are exchanged through LDS.
 // Always accumulates into y (the x pass ran first).  Grid: (ceil(nx/TX), n_outer).
 // DIR (1 = y, 2 = z) only tags the instantiation so profilers list the two passes separately.
-// SLAB = true (z lines of a slab with interfaces): the kernel works on the interior chain of the
+// SLAB = true (z lines of a slab with interfaces, RT0-P0): the kernel works on the interior chain of the
 // slab-local line.  mode 1 = endpoint response (partition method, step 1): solve with the plain
-// neighbour cells as boundary data, emit c_lo = -beta x_edge - a_lo u_first, c_hi = beta x_edge - a_hi u_last,
+// neighbour cells as boundary data, emit c_lo = -x_edge - a_lo u_first, c_hi = x_edge - a_hi u_last,
 // touch no y.  mode 2 = final solve with the separator values u_lo/u_hi folded into the boundary data,
 // accumulate y on the chain cells and on the edge cells.
 struct SlabArgs {
@@ -413,14 +474,16 @@ struct SlabArgs {
     const double *alo, *ahi, *ulo, *uhi;      // per line
     double *clo, *chi;                        // per line (mode 1 outputs)
 };
-template <int SEG, int DIR, bool SLAB>
-__global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ L,
-                          const double *__restrict__ DR, const double *__restrict__ D0, int n, long sl,
-                          long outer_stride, int nx, int TX, int NSEG, double beta, int last,
-                          double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa)
+template <int SEG, int DIR, bool SLAB, int NB>
+__global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+                          const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
+                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa)
 {
+    static_assert(!(SLAB && NB > 0), "slabs are RT0-P0");
     extern __shared__ double sm[];
     if (cg && cg->done) return;
+    const double *__restrict__ x = ma.x[0];
+    double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
     double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T, *sred = sm + 4 * T + TX;
     const int tid = threadIdx.x, ixl = tid % TX, seg = tid / TX;
@@ -438,13 +501,15 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
         edge_lo = base; edge_hi = base + (long)(nloc - 1) * sl;
         base += (long)fs * sl;
         if (valid) {
-            if (sa.if_lo) { a_lo = sa.alo[lineid]; x_before = x[edge_lo]; if (sa.mode == 2) { u_lo = sa.ulo[lineid]; x_before -= (a_lo / beta) * u_lo; } }
-            if (sa.if_hi) { a_hi = sa.ahi[lineid]; x_after = x[edge_hi]; if (sa.mode == 2) { u_hi = sa.uhi[lineid]; x_after += (a_hi / beta) * u_hi; } }
+            if (sa.if_lo) { a_lo = sa.alo[lineid]; x_before = x[edge_lo]; if (sa.mode == 2) { u_lo = sa.ulo[lineid]; x_before -= a_lo * u_lo; } }
+            if (sa.if_hi) { a_hi = sa.ahi[lineid]; x_after = x[edge_hi]; if (sa.mode == 2) { u_hi = sa.uhi[lineid]; x_after += a_hi * u_hi; } }
         }
     }
     const bool wr = !SLAB || sa.mode == 2;
     const int c0 = seg * SEG;
-    double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];
+    double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];          // xv: x_0 moment; for NB > 0 xL / xR are derived below
+    double x1[NB > 0 ? SEG : 1], x2[NB > 1 ? SEG : 1], icv[NB > 0 ? SEG : 1];
+    double xLn = 0.0;                                            // xL of the first cell of the next segment
 #pragma unroll
     for (int i = 0; i <= SEG; ++i) {
         const int c = c0 + i; const bool ok = valid && c < n;
@@ -453,15 +518,44 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
         if (SLAB && valid && c == n) xv[i] = x_after;
         Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) { Rv[i] = ok ? DR[a] : 0.0; yo[i] = (ok && wr) ? y[a] : 0.0; }
+        if (NB > 0) {
+            const double v1 = ok ? ma.x[1][a] : 0.0;
+            const double v2 = (NB > 1 && ok) ? ma.x[2][a] : 0.0;
+            if (i < SEG) {
+                x1[i] = v1; if (NB > 1) x2[i] = v2;
+                // cell coordinates for 1/c_e = D / factor_dir
+                int cx = ix, cy = 0, cz = 0;
+                if (DIR == 1) { cy = c; cz = blockIdx.y; } else { cy = blockIdx.y; cz = c; }
+                icv[i] = ok ? ma.D[a] / geom_factor(G, DIR, cx, cy, cz) : 0.0;
+            } else {
+                xLn = xv[i] + ma.eL[0] * ma.Gc[0] * v1 + (NB > 1 ? ma.eL[1] * ma.Gc[1] * v2 : 0.0);
+            }
+        }
     }
     double dinv_s = 0.0;
     if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
     double t[SEG];
     double P = 1.0, lz = 0.0;
+    double xL0 = xv[0];                                          // xL of this segment's first cell
+    if (NB == 0) {
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { t[i] = beta * (xv[i] - xv[i + 1]); lz = t[i] - Lv[i] * lz; P = -Lv[i] * P; }
+        for (int i = 0; i < SEG; ++i) t[i] = xv[i] - xv[i + 1];
+    } else {
+        double xLc[SEG + 1], xRc[SEG];
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const double g1 = ma.Gc[0] * x1[i], g2 = NB > 1 ? ma.Gc[1] * x2[i] : 0.0;
+            xLc[i] = xv[i] + ma.eL[0] * g1 + (NB > 1 ? ma.eL[1] * g2 : 0.0);
+            xRc[i] = xv[i] - ma.eR[0] * g1 - (NB > 1 ? ma.eR[1] * g2 : 0.0);
+        }
+        xLc[SEG] = xLn; xL0 = xLc[0];
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) t[i] = xRc[i] - xLc[i + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { lz = t[i] - Lv[i] * lz; P = -Lv[i] * P; }
     sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz;
-    if (seg == 0) sZ0[ixl] = beta * (x_before - xv[0]);
+    if (seg == 0) sZ0[ixl] = x_before - xL0;
     __syncthreads();
     double z = sZ0[ixl];
     for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
@@ -483,121 +577,37 @@ __global__ void k_schur_s(const double *__restrict__ x, double *__restrict__ y, 
     if (wr) {
 #pragma unroll
         for (int i = 0; i < SEG; ++i) {
-            const double yv = yo[i] + beta * (w[i] - (i == 0 ? ulo : w[i > 0 ? i - 1 : 0]));
+            const double lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
+            const double yv = yo[i] + ma.Ta * (w[i] - lo);
             const int c = c0 + i;
-            if (valid && c < n) { y[base + (long)c * sl] = yv; dot += xv[i] * yv; }
+            if (valid && c < n) {
+                const long a = base + (long)c * sl;
+                y[a] = yv; dot += xv[i] * yv;
+                if (NB > 0) {
+                    const double v = ma.Gc[0] * x1[i] * ma.iM[0] * icv[i] - (ma.eL[0] * lo + ma.eR[0] * w[i]);
+                    const double y1 = ma.y[1][a] + ma.Ta * ma.Gc[0] * v;
+                    ma.y[1][a] = y1; dot += x1[i] * y1;
+                }
+                if (NB > 1) {
+                    const double v = ma.Gc[1] * x2[i] * ma.iM[1] * icv[i] - (ma.eL[1] * lo + ma.eR[1] * w[i]);
+                    const double y2 = ma.y[2][a] + ma.Ta * ma.Gc[1] * v;
+                    ma.y[2][a] = y2; dot += x2[i] * y2;
+                }
+            }
         }
     }
     if (SLAB) {
         // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1
         if (valid && seg == 0 && sa.if_lo) {
-            if (sa.mode == 1) sa.clo[lineid] = -beta * x[edge_lo] - a_lo * ulo;
-            else { const double xe = x[edge_lo]; const double yv = y[edge_lo] + beta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv; }
+            if (sa.mode == 1) sa.clo[lineid] = -x[edge_lo] - a_lo * ulo;
+            else { const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv; }
         }
         if (valid && sa.if_hi && c0 <= n - 1 && n - 1 < c0 + SEG) {
             double ulast = 0.0;
 #pragma unroll
             for (int i = 0; i < SEG; ++i) if (c0 + i == n - 1) ulast = w[i];
-            if (n == 0) ulast = ulo;
-            if (sa.mode == 1) sa.chi[lineid] = beta * x[edge_hi] - a_hi * ulast;
-            else { const double xe = x[edge_hi]; const double yv = y[edge_hi] + beta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv; }
-        }
-    }
-    if (last && partials) {
-        const double s = block_sum(dot, sred);
-        if (tid == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
-    }
-}
-
-// Same algorithm, two adjacent x-columns (two independent lines) per thread: every access is a 16-byte
-// double2, so one wave instruction moves TXP*16 contiguous bytes per segment row (1 KiB at TXP = 64).
-// Requires nx even.  Thread = (ix pair, segment); TXP pairs per block row.
-template <int SEG, int DIR>
-__global__ void k_schur_s2(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ L,
-                           const double *__restrict__ DR, const double *__restrict__ D0, int n, long sl,
-                           long outer_stride, int nx, int TXP, int NSEG, double beta, int last,
-                           double *__restrict__ partials, const CgScalars *__restrict__ cg)
-{
-    extern __shared__ double sm[];
-    if (cg && cg->done) return;
-    const int T = TXP * NSEG;
-    double2 *sA = reinterpret_cast<double2 *>(sm), *sB = sA + T, *sA2 = sA + 2 * T, *sB2 = sA + 3 * T, *sZ0 = sA + 4 * T;
-    double *sred = reinterpret_cast<double *>(sZ0 + TXP);
-    const int tid = threadIdx.x, ixl = tid % TXP, seg = tid / TXP;
-    const int ix = (blockIdx.x * TXP + ixl) * 2;
-    const bool valid = ix < nx;
-    const long base = (long)blockIdx.y * outer_stride + ix;
-    const int c0 = seg * SEG;
-    const double2 zero2 = make_double2(0.0, 0.0);
-    double2 xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];
-#pragma unroll
-    for (int i = 0; i <= SEG; ++i) {
-        const int c = c0 + i; const bool ok = valid && c < n;
-        const long a = base + (long)c * sl;
-        xv[i] = ok ? *reinterpret_cast<const double2 *>(x + a) : zero2;
-        Lv[i] = ok ? *reinterpret_cast<const double2 *>(L + a) : zero2;
-        if (i < SEG) {
-            Rv[i] = ok ? *reinterpret_cast<const double2 *>(DR + a) : zero2;
-            yo[i] = ok ? *reinterpret_cast<const double2 *>(y + a) : zero2;
-        }
-    }
-    double2 dinv_s = zero2;
-    if (valid && c0 < n)
-        dinv_s = c0 == 0 ? *reinterpret_cast<const double2 *>(D0 + (long)blockIdx.y * nx + ix)
-                         : *reinterpret_cast<const double2 *>(DR + base + (long)(c0 - 1) * sl);
-    double2 t[SEG];
-    double2 P = make_double2(1.0, 1.0), lz = zero2;
-#pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-        t[i].x = beta * (xv[i].x - xv[i + 1].x); t[i].y = beta * (xv[i].y - xv[i + 1].y);
-        lz.x = t[i].x - Lv[i].x * lz.x; lz.y = t[i].y - Lv[i].y * lz.y;
-        P.x = -Lv[i].x * P.x; P.y = -Lv[i].y * P.y;
-    }
-    sA[seg * TXP + ixl] = P; sB[seg * TXP + ixl] = lz;
-    if (seg == 0) sZ0[ixl] = make_double2(-beta * xv[0].x, -beta * xv[0].y);
-    __syncthreads();
-    double2 z = sZ0[ixl];
-    for (int s = 0; s < seg; ++s) {
-        const double2 a = sA[s * TXP + ixl], b = sB[s * TXP + ixl];
-        z.x = a.x * z.x + b.x; z.y = a.y * z.y + b.y;
-    }
-    const double2 zin = z;
-    double2 w[SEG];
-#pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-        z.x = t[i].x - Lv[i].x * z.x; z.y = t[i].y - Lv[i].y * z.y;
-        w[i].x = z.x * Rv[i].x; w[i].y = z.y * Rv[i].y;
-    }
-    double2 Q = make_double2(1.0, 1.0), lu = zero2;
-#pragma unroll
-    for (int i = SEG - 1; i >= 0; --i) {
-        lu.x = w[i].x - Lv[i + 1].x * lu.x; lu.y = w[i].y - Lv[i + 1].y * lu.y;
-        Q.x = -Lv[i + 1].x * Q.x; Q.y = -Lv[i + 1].y * Q.y;
-    }
-    sA2[seg * TXP + ixl] = Q; sB2[seg * TXP + ixl] = lu;
-    __syncthreads();
-    double2 u = zero2;
-    for (int s = NSEG - 1; s > seg; --s) {
-        const double2 a = sA2[s * TXP + ixl], b = sB2[s * TXP + ixl];
-        u.x = a.x * u.x + b.x; u.y = a.y * u.y + b.y;
-    }
-#pragma unroll
-    for (int i = SEG - 1; i >= 0; --i) {
-        u.x = w[i].x - Lv[i + 1].x * u.x; u.y = w[i].y - Lv[i + 1].y * u.y;
-        w[i] = u;
-    }
-    double2 ulo;
-    ulo.x = zin.x * dinv_s.x - Lv[0].x * w[0].x; ulo.y = zin.y * dinv_s.y - Lv[0].y * w[0].y;
-    double dot = 0.0;
-#pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-        const double2 lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
-        double2 yv;
-        yv.x = yo[i].x + beta * (w[i].x - lo.x); yv.y = yo[i].y + beta * (w[i].y - lo.y);
-        const int c = c0 + i;
-        if (valid && c < n) {
-            *reinterpret_cast<double2 *>(y + base + (long)c * sl) = yv;
-            dot += xv[i].x * yv.x + xv[i].y * yv.y;
+            if (sa.mode == 1) sa.chi[lineid] = x[edge_hi] - a_hi * ulast;
+            else { const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv; }
         }
     }
     if (last && partials) {
@@ -665,13 +675,16 @@ struct ScatterArgs { const double *M[64]; int ng; };
 // rhs = chi_g * total_fiss / k + sum_{gp != g} M_scatter[g<-gp] phi_gp  (Gauss-Seidel: gp < g from the new
 // iterate, gp > g from the old one) (:1716-1726).  If sinv != NULL the diagonal solve phi = S_inv * rhs is
 // fused (:607-613) and written to out, otherwise out = rhs.
+// n = DOFs per group (SoA [p][e]), ncell = cells: chi is per cell; for P>=1 elements with |chi/k| < 1e-14 are skipped (:1551).
 __global__ __launch_bounds__(256) void k_group_rhs(ScatterArgs sa, int g, const double *__restrict__ chi,
                                                    const double *__restrict__ tf, double inv_k,
                                                    const double *__restrict__ phi_new, const double *__restrict__ phi_old,
-                                                   const double *__restrict__ sinv, double *__restrict__ out, long n)
+                                                   const double *__restrict__ sinv, double *__restrict__ out, long n, long ncell)
 {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-        double v = inv_k * (chi[i] * tf[i]);
+        double v;
+        if (n == ncell) v = inv_k * (chi[i] * tf[i]);
+        else { const double cv = chi[i % ncell] * inv_k; v = fabs(cv) < 1e-14 ? 0.0 : cv * tf[i]; }
         for (int gp = 0; gp < sa.ng; ++gp) {
             if (gp == g || !sa.M[gp]) continue;
             const double *ph = gp < g ? phi_new : phi_old;
@@ -738,8 +751,9 @@ __global__ void k_coarsen(const double *__restrict__ fine, double *__restrict__ 
     }
 }
 // prolongation: piecewise-constant injection (src/NeutFEM.cpp:2585-2606)
+// fine has gstride doubles per group (nloc*Nf, SoA): only the P0 moment is written, the rest is zeroed by the caller
 __global__ void k_prolong(const double *__restrict__ coarse, double *__restrict__ fine, int nx, int ny, int nz, int rx,
-                          int ry, int rz, int ng)
+                          int ry, int rz, int ng, long gstride)
 {
     const long Nf = (long)nx * ny * nz;
     const int nxc = nx / rx, nyc = ny / ry; const long Nc = (long)nxc * nyc * (nz / rz);
@@ -747,7 +761,7 @@ __global__ void k_prolong(const double *__restrict__ coarse, double *__restrict_
     if (e >= Nf) return;
     const int ix = (int)(e % nx), iy = (int)((e / nx) % ny), iz = (int)(e / ((long)nx * ny));
     const long ec = ((long)(iz / rz) * nyc + iy / ry) * nxc + ix / rx;
-    for (int g = 0; g < ng; ++g) fine[g * Nf + e] = coarse[g * Nc + ec];
+    for (int g = 0; g < ng; ++g) fine[g * gstride + e] = coarse[g * Nc + ec];
 }
 
 // J reconstruction (src/solvers.cpp:227-228 full path: J = -A^-1 B^T phi ; src/NeutFEM.cpp:620-633 diagonal
@@ -764,14 +778,13 @@ __global__ void k_flux_to_J(Geom G, int d, const double *__restrict__ D, const d
     else if (d == 1) { n = G.ny; ix = (int)(line % G.nx); iz = (int)(line / G.nx); base = iz * nxy + ix; sl = G.nx;
                        fbase = (long)iz * (G.ny + 1) * G.nx + ix; fsl = G.nx; }
     else { n = G.nz; ix = (int)(line % G.nx); iy = (int)(line / G.nx); base = line; sl = nxy; fbase = line; fsl = nxy; }
-    const double beta = G.beta;
     if (!diag) {
-        double z = -beta * phi[base];
+        double z = -phi[base];
         J[fbase] = z * D0[line];
         double xc = phi[base];
         for (int c = 0; c < n; ++c) {
             const double xn = c + 1 < n ? phi[base + (long)(c + 1) * sl] : 0.0;
-            z = beta * (xc - xn) - L[base + (long)c * sl] * z;
+            z = (xc - xn) - L[base + (long)c * sl] * z;
             J[fbase + (long)(c + 1) * fsl] = z * DR[base + (long)c * sl];
             xc = xn;
         }
@@ -790,8 +803,8 @@ __global__ void k_flux_to_J(Geom G, int d, const double *__restrict__ D, const d
             double Aff = a2p + a2;
             if (f == 0 && G.dir_lo[d]) { *ci = 0; Aff += dirichlet_term(G, d, ix, iy, iz, Dc); }
             if (f == n && G.dir_hi[d]) { *ci = n - 1; Aff += dirichlet_term(G, d, ix, iy, iz, Dp); }
-            const double tt = beta * (xp - xc);
-            J[fbase + (long)f * fsl] = fabs(Aff) < 1e-14 ? 0.0 : tt / Aff;
+            const double tt = xp - xc;                           // (B^T phi)_f / A_ff = T0 (..) / (T0 A_unit)
+            J[fbase + (long)f * fsl] = fabs(G.T0 * Aff) < 1e-14 ? 0.0 : tt / Aff;
             a2p = a2; xp = xc; Dp = Dc;
         }
     }
