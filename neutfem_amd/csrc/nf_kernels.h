@@ -517,7 +517,7 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
         xv[i] = ok ? x[a] : 0.0;
         if (SLAB && valid && c == n) xv[i] = x_after;
         Lv[i] = ok ? L[a] : 0.0;
-        if (i < SEG) { Rv[i] = ok ? DR[a] : 0.0; yo[i] = (ok && wr) ? y[a] : 0.0; }
+        if (i < SEG) Rv[i] = ok ? DR[a] : 0.0;
         if (NB > 0) {
             const double v1 = ok ? ma.x[1][a] : 0.0;
             const double v2 = (NB > 1 && ok) ? ma.x[2][a] : 0.0;
@@ -567,6 +567,9 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
     sA2[seg * TX + ixl] = Q; sB2[seg * TX + ixl] = lu;
+    // y is only needed by the output stage: issue its loads here so they fly during the barrier + backward scan
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (valid && c < n && wr) ? y[base + (long)c * sl] : 0.0; }
     __syncthreads();
     double u = 0.0;
     for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];

@@ -39,7 +39,8 @@ struct nfo {
     long nJx, nJy, nJz, nJface, nJint, nJ, nPhi;
     int nq; double qp[MAXQ], qw[MAXQ];
     /* XS + solution (host) */
-    double *D, *SigR, *NSF, *KSF, *Chi, *SRC, *SigS, *phi, *J;
+    double *D, *SigR, *NSF, *KSF, *Chi, *SRC, *SigS, *phi, *J, *phi_adj;
+    double last_keff_adj; int has_valid_adjoint;
     int bc_set[8], bc_type[8]; double bc_val[8];
     double tol_keff, tol_flux, tol_L2; int max_outer, max_inner;
     int solver_type, solver_type_pushed;    /* NeutFEM.cpp:126 vs solvers.cpp:68 */
@@ -59,6 +60,7 @@ struct nfo {
     double **Aband;                         /* per group: unfactored copy (for refactor / diag) */
     double **Cd;                            /* per group: nPhi diagonal of C */
     double **Mf;                            /* per group: nPhi diagonal of M_fiss */
+    double **Mchi;                          /* per group: nPhi diagonal of the chi-weighted mass matrix (adjoint) */
     double **Ms;                            /* ng*ng  : nPhi diagonal of M_scatter[g_to*ng+g_from] or NULL if empty */
     double **Sinv;                          /* diag cache per group */
     int diag_valid;
@@ -365,6 +367,9 @@ nfo_t *nfo_create(int rt_order, int p_order, int ng, int nxb, const double *xb, 
     if (ng > 0) for (long e = 0; e < ne; ++e) h->Chi[e] = 1.0;
     h->phi = (double *)malloc(sizeof(double) * ng * h->nPhi); h->J = (double *)calloc(ng * h->nJ, sizeof(double));
     for (long i = 0; i < ng * h->nPhi; ++i) h->phi[i] = 1.0;
+    h->phi_adj = (double *)malloc(sizeof(double) * ng * h->nPhi);
+    for (long i = 0; i < ng * h->nPhi; ++i) h->phi_adj[i] = 1.0;
+    h->last_keff_adj = 1.0; h->has_valid_adjoint = 0;
     h->tol_keff = h->tol_flux = h->tol_L2 = 1e-5; h->max_outer = 200; h->max_inner = 1000;
     h->solver_type = 6; h->solver_type_pushed = 0;             /* BICGSTAB shown, DIRECT_LU used (quirk 11) */
     h->schur_tol = 1e-10; h->schur_maxit = 1000;               /* solvers.cpp:67-76 */
@@ -386,9 +391,9 @@ nfo_t *nfo_create(int rt_order, int p_order, int ng, int nxb, const double *xb, 
 static void free_built(nfo_t *h)
 {
     if (!h->built) return;
-    for (int g = 0; g < h->ng; ++g) { free(h->band[g]); free(h->Aband[g]); free(h->Cd[g]); free(h->Mf[g]); if (h->Sinv && h->Sinv[g]) free(h->Sinv[g]); }
+    for (int g = 0; g < h->ng; ++g) { free(h->band[g]); free(h->Aband[g]); free(h->Cd[g]); free(h->Mf[g]); free(h->Mchi[g]); if (h->Sinv && h->Sinv[g]) free(h->Sinv[g]); }
     for (int i = 0; i < h->ng * h->ng; ++i) free(h->Ms[i]);
-    free(h->band); free(h->Aband); free(h->Cd); free(h->Mf); free(h->Ms); free(h->Sinv);
+    free(h->band); free(h->Aband); free(h->Cd); free(h->Mf); free(h->Mchi); free(h->Ms); free(h->Sinv);
     free(h->eJ); free(h->wt); free(h->wu);
     h->built = 0;
 }
@@ -397,7 +402,7 @@ void nfo_destroy(nfo_t *h)
     if (!h) return;
     free_built(h);
     free(h->xb); free(h->yb); free(h->zb); free(h->hx); free(h->hy); free(h->hz);
-    free(h->D); free(h->SRC); free(h->SigR); free(h->NSF); free(h->KSF); free(h->Chi); free(h->SigS); free(h->phi); free(h->J);
+    free(h->D); free(h->SRC); free(h->SigR); free(h->NSF); free(h->KSF); free(h->Chi); free(h->SigS); free(h->phi); free(h->J); free(h->phi_adj);
     for (int d = 0; d < 3; ++d) free(h->Ahat[d]);
     free(h->Bhat); free(h->Chat); free(h->hist_cg);
     free(h);
@@ -420,7 +425,7 @@ double *nfo_array(nfo_t *h, const char *name, long *n)
 #define A(s, p, len) if (!strcmp(name, s)) { if (n) *n = (len); return (p); }
     A("D", h->D, ng * ne) A("SigR", h->SigR, ng * ne) A("NSF", h->NSF, ng * ne) A("KSF", h->KSF, ng * ne)
     A("Chi", h->Chi, ng * ne) A("SRC", h->SRC, ng * ne) A("SigS", h->SigS, ng * ng * ne)
-    A("phi", h->phi, ng * h->nPhi) A("J", h->J, ng * h->nJ)
+    A("phi", h->phi, ng * h->nPhi) A("J", h->J, ng * h->nJ) A("phi_adj", h->phi_adj, ng * h->nPhi)
     A("hist_k", h->hist_k, h->last_outer) A("hist_dk", h->hist_dk, h->last_outer) A("hist_dphi", h->hist_dphi, h->last_outer)
     A("hist_cg", h->hist_cg, (long)h->last_outer * ng)
 #undef A
@@ -437,10 +442,11 @@ void nfo_set_tol(nfo_t *h, double a, double b, double c, int mo, int mi)
 void nfo_set_linear_solver(nfo_t *h, int type) { h->solver_type = type; h->solver_type_pushed = 1; }
 void nfo_reset_flux(nfo_t *h)
 {
-    for (long i = 0; i < h->ng * h->nPhi; ++i) h->phi[i] = 1.0;
+    for (long i = 0; i < h->ng * h->nPhi; ++i) { h->phi[i] = 1.0; h->phi_adj[i] = 1.0; }
     memset(h->J, 0, sizeof(double) * h->ng * h->nJ);
-    h->has_valid_keff = 0;
+    h->has_valid_keff = 0; h->has_valid_adjoint = 0;
 }
+double nfo_last_keff_adjoint(const nfo_t *h) { return h->last_keff_adj; }
 void nfo_set_refactor_each_solve(nfo_t *h, int on) { h->refactor_each = on; }
 double nfo_last_keff(const nfo_t *h) { return h->last_keff; }
 
@@ -524,7 +530,7 @@ int nfo_build(nfo_t *h)
     const int ng = h->ng, nJl = h->nJloc, nP = h->nloc, nper = h->nper, dim = h->dim, bw = h->bw, w = bw + 1;
     const long ne = h->ne, nJ = h->nJ;
     h->band = (double **)calloc(ng, sizeof(double *)); h->Aband = (double **)calloc(ng, sizeof(double *));
-    h->Cd = (double **)calloc(ng, sizeof(double *)); h->Mf = (double **)calloc(ng, sizeof(double *));
+    h->Cd = (double **)calloc(ng, sizeof(double *)); h->Mf = (double **)calloc(ng, sizeof(double *)); h->Mchi = (double **)calloc(ng, sizeof(double *));
     h->Ms = (double **)calloc((size_t)ng * ng, sizeof(double *)); h->Sinv = (double **)calloc(ng, sizeof(double *));
     h->eJ = (int *)malloc(sizeof(int) * ne * nJl);
     h->wt = (double *)malloc(sizeof(double) * nJ); h->wu = (double *)malloc(sizeof(double) * nJ);
@@ -576,6 +582,7 @@ int nfo_build(nfo_t *h)
         /* AssembleC(g): NeutFEM.cpp:1163-1202 ; C-hat is diagonal after the 1e-14 drop */
         h->Cd[g] = (double *)calloc(h->nPhi, sizeof(double));
         h->Mf[g] = (double *)calloc(h->nPhi, sizeof(double));
+        h->Mchi[g] = (double *)calloc(h->nPhi, sizeof(double));
         for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
             long e = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix;
             double fac[3], detJ; geom_factors(h, ix, iy, iz, fac, &detJ);
@@ -585,6 +592,10 @@ int nfo_build(nfo_t *h)
                 double c = sig * detJ * h->Chat[p * nP + p];
                 h->Cd[g][e * nP + p] = fabs(c) > 1e-14 ? c : 0.0;
             }
+            /* M_chi = AssembleWeightedMassMatrix(chi_g): NeutFEM.cpp:432-439,1495-1529 (always through C_loc, also for P0) */
+            { double chi = h->Chi[g * ne + e];
+              if (!(fabs(chi) < 1e-14))
+                  for (int p = 0; p < nP; ++p) { double c = chi * detJ * h->Chat[p * nP + p]; h->Mchi[g][e * nP + p] = fabs(c) > 1e-14 ? c : 0.0; } }
             /* AssembleFissionMatrix: NeutFEM.cpp:1204-1252 */
             if (h->m == 0) { if (fabs(nsf) > 1e-14) h->Mf[g][e] = nsf * vol; }
             else if (!(fabs(nsf) < 1e-14))
@@ -823,6 +834,85 @@ double nfo_solve_keff(nfo_t *h, int use_coarse_init, const int *factors, int nfa
     }
     cheb_free(&acc); free(tf); free(old); free(Jt);
     h->has_valid_keff = 1; h->last_keff = keff;
+    return keff;
+}
+
+/* SolveAdjoint, src/NeutFEM.cpp:1877-2082 (+ BuildFissionRHSAdjoint :1568-1589, SolveGroupInternalAdjoint :2107-2126) */
+double nfo_solve_adjoint(nfo_t *h, int normalize_to_direct, int use_direct_keff)
+{
+    const int ng = h->ng; const long nP = h->nPhi, ne = h->ne; const int dpe = h->nloc;
+    double keff = 1.0;
+    if (use_direct_keff && h->has_valid_keff) keff = h->last_keff;
+    double *pa = h->phi_adj;
+    { double n0 = sqrt((double)(ng * nP)); for (long i = 0; i < ng * nP; ++i) pa[i] = 1.0 / n0; }   /* setConstant(1) / norm */
+    cheb_t acc; cheb_init(&acc, 15, 0.98, ng * nP);
+    double *tca = (double *)malloc(sizeof(double) * nP * 3), *rhs = tca + nP, *sol = rhs + nP;
+    double *old = (double *)malloc(sizeof(double) * ng * nP);
+    double *nsft = (double *)calloc(ne, sizeof(double));
+    for (long e = 0; e < ne; ++e) for (int g = 0; g < ng; ++g) nsft[e] += h->NSF[g * ne + e];
+    h->last_outer = 0; h->last_cg_total = 0;
+    for (int it = 0; it < h->max_outer; ++it) {
+        memcpy(old, pa, sizeof(double) * ng * nP);
+        memset(tca, 0, sizeof(double) * nP);
+        for (int g = 0; g < ng; ++g) for (long i = 0; i < nP; ++i) tca[i] += h->Mchi[g][i] * pa[g * nP + i];
+        double prod_old = 0.0; for (long e = 0; e < ne; ++e) prod_old += nsft[e] * tca[e * dpe];
+        for (int g = 0; g < ng; ++g) {
+            memset(rhs, 0, sizeof(double) * nP);
+            const double inv_k = 1.0 / keff;
+            if (dpe == 1) for (long e = 0; e < ne; ++e) rhs[e] += inv_k * (h->NSF[g * ne + e] * tca[e]);
+            else for (long e = 0; e < ne; ++e) {
+                double nv = h->NSF[g * ne + e] * inv_k;
+                if (fabs(nv) < 1e-14) continue;
+                for (int d = 0; d < dpe; ++d) rhs[e * dpe + d] += nv * tca[e * dpe + d];
+            }
+            for (int gp = 0; gp < ng; ++gp) {
+                if (gp == g) continue;
+                const double *M = h->Ms[gp * ng + g];                       /* transposed block index (:1944-1950) */
+                if (!M) continue;
+                for (long i = 0; i < nP; ++i) rhs[i] += M[i] * pa[gp * nP + i];
+            }
+            int its = nfo_solve_group(h, g, rhs, sol, NULL);
+            memcpy(pa + g * nP, sol, sizeof(double) * nP);
+            if (it < MAXHIST) h->hist_cg[(long)it * ng + g] = its;
+            h->last_cg_total += its;
+        }
+        memset(tca, 0, sizeof(double) * nP);
+        for (int g = 0; g < ng; ++g) for (long i = 0; i < nP; ++i) tca[i] += h->Mchi[g][i] * pa[g * nP + i];
+        double prod_new = 0.0; for (long e = 0; e < ne; ++e) prod_new += nsft[e] * tca[e * dpe];
+        double keff_new = keff, dk;
+        if (!use_direct_keff || !h->has_valid_keff) {
+            if (fabs(prod_old) > 1e-14 && it > 0) keff_new = keff * (prod_new / prod_old);
+            dk = fabs(keff_new - keff); keff = keff_new;
+        } else dk = 0.0;
+        double nsq = 0.0, dsq = 0.0;
+        for (long i = 0; i < ng * nP; ++i) { nsq += pa[i] * pa[i]; double d = pa[i] - old[i]; dsq += d * d; }
+        const double dphi = sqrt(dsq) / sqrt(nsq), norm = sqrt(nsq);
+        if (norm > 1e-14) for (long i = 0; i < ng * nP; ++i) pa[i] /= norm;
+        if (!use_direct_keff && it >= 5) cheb_apply(&acc, pa);
+        if (it < MAXHIST) { h->hist_k[it] = keff; h->hist_dk[it] = dk; h->hist_dphi[it] = dphi; }
+        h->last_outer = it + 1;
+        int conv = dphi < h->tol_flux;
+        if (!use_direct_keff) conv = conv && (dk < h->tol_keff);
+        if (conv) break;
+    }
+    if (normalize_to_direct && h->has_valid_keff) {                         /* <phi, phi+> = 1 (:2020-2066) */
+        double ip = 0.0; const int n = h->m + 1;
+        for (int g = 0; g < ng; ++g) for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
+            long e = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix;
+            double vol = h->hx[ix] * h->hy[iy] * h->hz[iz];
+            for (int d = 0; d < dpe; ++d) {
+                int i, j, kk;
+                if (h->dim == 1) { i = d; j = 0; kk = 0; } else if (h->dim == 2) { i = d % n; j = d / n; kk = 0; } else { i = d % n; j = (d / n) % n; kk = d / (n * n); }
+                double w = (2.0 / (2.0 * i + 1.0)) / 2.0;
+                if (h->dim >= 2) w *= (2.0 / (2.0 * j + 1.0)) / 2.0;
+                if (h->dim >= 3) w *= (2.0 / (2.0 * kk + 1.0)) / 2.0;
+                ip += h->phi[g * nP + e * dpe + d] * pa[g * nP + e * dpe + d] * vol * w;
+            }
+        }
+        if (fabs(ip) > 1e-14) for (long i = 0; i < ng * nP; ++i) pa[i] /= ip;
+    }
+    cheb_free(&acc); free(tca); free(old); free(nsft);
+    h->has_valid_adjoint = 1; h->last_keff_adj = keff;
     return keff;
 }
 

@@ -36,7 +36,7 @@ void nfo_destroy(nfo_t *h);
  * "n_phi","n_J","n_Jx","n_Jy","n_Jz","nq","last_outer","last_cg_total","coarse_outer" */
 long nfo_info(const nfo_t *h, const char *key);
 /* host arrays (owned by the handle, writable): "D","SigR","NSF","KSF","Chi","SRC","SigS",
- * "phi","J","hist_k","hist_dk","hist_dphi","hist_cg" ; *n receives the length */
+ * "phi","J","phi_adj","hist_k","hist_dk","hist_dphi","hist_cg" ; *n receives the length */
 double *nfo_array(nfo_t *h, const char *name, long *n);
 
 void nfo_set_bc(nfo_t *h, int attr, int type, double value);                 /* src/NeutFEM.cpp:337-345 */
@@ -65,6 +65,9 @@ double nfo_solve_coarse(nfo_t *h, const int *factors, int nfactors, double *phi_
 /* src/NeutFEM.cpp:483-597 ; returns S_inv for group g (ne entries) or NULL */
 const double *nfo_diag_cache(nfo_t *h, int g);
 double nfo_last_keff(const nfo_t *h);
+/* src/NeutFEM.cpp:1877-2082 ; the adjoint flux is the array "phi_adj" */
+double nfo_solve_adjoint(nfo_t *h, int normalize_to_direct, int use_direct_keff);
+double nfo_last_keff_adjoint(const nfo_t *h);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,10 @@ def lib():
         L.nfo_diag_cache.argtypes = [vp, C.c_int]
         L.nfo_last_keff.restype = C.c_double
         L.nfo_last_keff.argtypes = [vp]
+        L.nfo_solve_adjoint.restype = C.c_double
+        L.nfo_solve_adjoint.argtypes = [vp, C.c_int, C.c_int]
+        L.nfo_last_keff_adjoint.restype = C.c_double
+        L.nfo_last_keff_adjoint.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -141,6 +145,16 @@ class OracleNeutFEM:
         return k, out
 
     def GetLastKeff(self): return self._L.nfo_last_keff(self._h)
+    def GetLastKeffAdjoint(self): return self._L.nfo_last_keff_adjoint(self._h)
+
+    def SolveAdjoint(self, normalize_to_direct=True, use_direct_keff=True):
+        return self._L.nfo_solve_adjoint(self._h, int(normalize_to_direct), int(use_direct_keff))
+
+    def phi_adj_dofs(self): return self._arr("phi_adj").reshape(self.ng, self.n_phi)
+
+    def get_flux_adj(self):
+        phi = self._arr("phi_adj").reshape(self.ng, self.ne, self.nloc)[:, :, 0]
+        return np.ascontiguousarray(phi).reshape(self._cellshape([self.ng]))
 
     # oracle-only probes
     def local_matrices(self, e, D, Sigma):
