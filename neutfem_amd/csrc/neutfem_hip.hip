@@ -1018,7 +1018,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     // SchurSolver type: DIRECT_* or n_phi < 200 -> "exact" solve (CG to 1e-14 stands in)
     const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (single && Ntot < 200);
     const double cg_tol = direct ? 1e-14 : o->tol_flux;           // SetTolerance forwards tol_flux (:334)
-    const int cg_max = direct ? 100000 : o->max_inner;
+    const int cg_max = direct ? (int)std::min<long>(20 * Ntot + 50, 2000000000L) : o->max_inner;   // CG ends in <= n steps in exact arithmetic
     // ChebyshevAccel(15, 0.98), src/solvers.cpp:664-700
     const int nmax = 15; const double sigma = 0.98;
     double ca[16], cbv[16];

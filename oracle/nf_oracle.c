@@ -691,7 +691,7 @@ int nfo_solve_group(nfo_t *h, int g, const double *rhs, double *phi, double *J)
         band_factor(h->band[g], h->nJ, h->bw);
     }
     int direct = !h->solver_type_pushed || h->solver_type <= 2 || h->nPhi < 200;   /* solvers.cpp:114-124 */
-    int its = direct ? cg_solve(h, g, rhs, phi, 1e-14, 100000)
+    int its = direct ? cg_solve(h, g, rhs, phi, 1e-14, (int)(20 * h->nPhi + 50))   /* CG terminates in <= n steps in exact arithmetic */
                      : cg_solve(h, g, rhs, phi, h->schur_tol, h->schur_maxit);
     if (J) {                                                   /* J = -A^-1 B^T phi, solvers.cpp:227-228 */
         apply_BT(h, phi, h->wt);
