@@ -299,8 +299,8 @@ class HipTeam:
     def build(self):
         for s in self.slabs: s.build()
 
-    def solve_keff(self, profile=False):
-        return self.head.solve_keff(profile=profile)
+    def solve_keff(self, use_coarse=False, factors=(), profile=False):
+        return self.head.solve_keff(use_coarse, factors, False, profile)
 
     def history(self): return self.head.history()
     def profile(self, name): return self.head.profile(name)

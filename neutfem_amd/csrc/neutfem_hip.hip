@@ -924,56 +924,75 @@ int nf_get_J(nf_handle S, double *J_host)
 // ---- SolveCoarse (src/NeutFEM.cpp:2380-2611) ---------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff, int *n_outer);
 
-// builds + solves the coarse problem on the device; the prolonged flux is written to d_dst (ng*N)
-static int coarse_init(nf_solver *S, const nf_keff_opts *o, double *k_coarse, double *d_dst, bool *done)
+// Builds + solves the coarse problem on the device (every local slab coarsens its own planes; the coarse slabs form a
+// team that shares the fine team's communicator); the prolonged flux of slab i is written to dsts[i] (ng*nphi).
+static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, const std::vector<double *> &dsts, bool *done)
 {
     *done = false;
-    nf_team *T = S->team;
-    const int dim = S->dim, ng = S->ng;
+    const int ns = (int)T->slabs.size();
+    nf_solver *S0 = T->slabs[0];
+    const int dim = S0->dim, ng = S0->ng;
     const int nf = o->n_coarse_factors;
     int rx = nf > 0 ? std::max(o->coarse_factors[0], 1) : 1;
     int ry = (nf > 1 && dim >= 2) ? std::max(o->coarse_factors[1], 1) : 1;
     int rz = (nf > 2 && dim >= 3) ? std::max(o->coarse_factors[2], 1) : 1;
-    if (S->nx % rx || S->ny % ry || S->nz % rz) return NF_OK;   // :2402-2407 -> (1.0, Sol_Phi_)
-    const int nxc = S->nx / rx, nyc = S->ny / ry, nzc = S->nz / rz;
-    std::vector<double> xc(nxc + 1), yc(dim >= 2 ? nyc + 1 : 1), zc(dim >= 3 ? nzc + 1 : 1);
-    for (int i = 0; i <= nxc; ++i) xc[i] = S->xb[i * rx];
-    if (dim >= 2) for (int j = 0; j <= nyc; ++j) yc[j] = S->yb[j * ry]; else yc[0] = 0.0;
-    if (dim >= 3) for (int kk = 0; kk <= nzc; ++kk) zc[kk] = S->zb[kk * rz]; else zc[0] = 0.0;
-    nf_handle C = nullptr;
-    NFCHK(nf_create(0, 0, ng, nxc + 1, xc.data(), (int)yc.size(), yc.data(), (int)zc.size(), zc.data(), S->device, &C));
-    for (int a = 0; a < 8; ++a) if (S->bc_set[a]) nf_set_bc(C, a, S->bc_type[a]);
-    const long Nc = C->N;
+    // :2402-2407 -> (1.0, Sol_Phi_).  On a decomposed mesh every slab must be divisible (a global decision is needed,
+    // so indivisible local slabs are an error rather than a silent fallback on some ranks only).
+    for (auto *S : T->slabs)
+        if (S->nx % rx || S->ny % ry || S->nz % rz) {
+            if (ns == 1 && T->nproc == 1) return NF_OK;
+            return fail(NF_ERR_ARG, "coarse factors (%d,%d,%d) do not divide slab %d x %d x %d", rx, ry, rz, S->nx, S->ny, S->nz);
+        }
+    std::vector<nf_handle> C(ns, nullptr);
     int rc = NF_OK;
-    auto coarsen = [&](const double *fine, double **coarse, int nfields) -> int {
-        NFCHK(dalloc(coarse, (size_t)Nc * nfields));
-        hipLaunchKernelGGL(k_coarsen, dim3((unsigned)((Nc + 127) / 128)), dim3(128), 0, T->stream, fine, *coarse, S->d_xb, S->d_yb, S->d_zb,
-                           dim, S->nx, S->ny, S->nz, rx, ry, rz, nfields);
-        return NF_OK;
-    };
-    rc = coarsen(S->d_D, &C->d_D, ng);
-    if (rc == NF_OK) rc = coarsen(S->d_SigR, &C->d_SigR, ng);
-    if (rc == NF_OK) rc = coarsen(S->d_NSF, &C->d_NSF, ng);
-    if (rc == NF_OK) rc = coarsen(S->d_Chi, &C->d_Chi, ng);
-    for (int i = 0; i < ng * ng && rc == NF_OK; ++i)
-        if (S->d_SigS[i]) rc = coarsen(S->d_SigS[i], &C->d_SigS[i], 1);    // mean of an all-zero block is zero
-    if (rc == NF_OK && hipStreamSynchronize(T->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "coarsen failed");
-    if (rc == NF_OK) { C->xs_uploaded = true; rc = nf_build(C); }
+    for (int i = 0; i < ns && rc == NF_OK; ++i) {
+        nf_solver *S = T->slabs[i];
+        const int nxc = S->nx / rx, nyc = S->ny / ry, nzc = S->nz / rz;
+        std::vector<double> xc(nxc + 1), yc(dim >= 2 ? nyc + 1 : 1), zc(dim >= 3 ? nzc + 1 : 1);
+        for (int a = 0; a <= nxc; ++a) xc[a] = S->xb[a * rx];
+        if (dim >= 2) for (int j = 0; j <= nyc; ++j) yc[j] = S->yb[j * ry]; else yc[0] = 0.0;
+        if (dim >= 3) for (int kk = 0; kk <= nzc; ++kk) zc[kk] = S->zb[kk * rz]; else zc[0] = 0.0;
+        rc = create_impl(0, 0, ng, nxc + 1, xc.data(), (int)yc.size(), yc.data(), (int)zc.size(), zc.data(), S->if_lo, S->if_hi, S->device, &C[i]);
+        if (rc != NF_OK) break;
+        for (int a = 0; a < 8; ++a) if (S->bc_set[a]) nf_set_bc(C[i], a, S->bc_type[a]);
+        const long Nc = C[i]->N;
+        auto coarsen = [&](const double *fine, double **coarse, int nfields) -> int {
+            NFCHK(dalloc(coarse, (size_t)Nc * nfields));
+            hipLaunchKernelGGL(k_coarsen, dim3((unsigned)((Nc + 127) / 128)), dim3(128), 0, T->stream, fine, *coarse, S->d_xb, S->d_yb, S->d_zb,
+                               dim, S->nx, S->ny, S->nz, rx, ry, rz, nfields);
+            return NF_OK;
+        };
+        rc = coarsen(S->d_D, &C[i]->d_D, ng);
+        if (rc == NF_OK) rc = coarsen(S->d_SigR, &C[i]->d_SigR, ng);
+        if (rc == NF_OK) rc = coarsen(S->d_NSF, &C[i]->d_NSF, ng);
+        if (rc == NF_OK) rc = coarsen(S->d_Chi, &C[i]->d_Chi, ng);
+        for (int b = 0; b < ng * ng && rc == NF_OK; ++b)
+            if (S->d_SigS[b]) rc = coarsen(S->d_SigS[b], &C[i]->d_SigS[b], 1);    // mean of an all-zero block is zero
+        if (rc == NF_OK && hipStreamSynchronize(T->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "coarsen failed");
+        if (rc == NF_OK) { C[i]->xs_uploaded = true; rc = nf_build(C[i]); }
+    }
+    if (rc == NF_OK && ns > 1) rc = nf_link_slabs(C.data(), ns);
+    nf_team *CT = rc == NF_OK ? C[0]->team : nullptr;
+    if (CT) { CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false; }
     double kc = 1.0; int nout = 0;
     if (rc == NF_OK) {
         nf_keff_opts co = *o;                                    // :2460-2467
         co.tol_keff = o->tol_keff * 10.0; co.tol_flux = o->tol_flux * 10.0; co.max_outer = o->max_outer / 2;
         co.use_coarse_init = 0; co.n_coarse_factors = 0; co.use_diagonal_solver = 0; co.solver_type_pushed = 1; co.profile = 0;
-        rc = solve_keff_impl(C->team, &co, &kc, &nout);
+        rc = solve_keff_impl(CT, &co, &kc, &nout);
     }
     if (rc == NF_OK) {
         T->coarse_outer = nout;
-        (void)hipMemsetAsync(d_dst, 0, (size_t)S->nphi * ng * sizeof(double), C->team->stream);   // higher moments 0 (:2585-2606)
-        hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, C->team->stream, C->d_phi, d_dst, S->nx, S->ny, S->nz, rx, ry, rz, ng, S->nphi);
-        if (hipStreamSynchronize(C->team->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            (void)hipMemsetAsync(dsts[i], 0, (size_t)S->nphi * ng * sizeof(double), CT->stream);   // higher moments 0 (:2585-2606)
+            hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, CT->stream, C[i]->d_phi, dsts[i], S->nx, S->ny, S->nz, rx, ry, rz, ng, S->nphi);
+        }
+        if (hipStreamSynchronize(CT->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
     }
     std::string keep = g_err;
-    nf_destroy(C);
+    if (CT) CT->comm = nullptr;                                  // borrowed: must not be destroyed with the coarse team
+    for (int i = ns - 1; i >= 0; --i) if (C[i]) nf_destroy(C[i]);
     if (rc != NF_OK) { g_err = keep; return rc; }
     *k_coarse = kc; *done = true;
     return NF_OK;
@@ -986,7 +1005,7 @@ int nf_solve_coarse(nf_handle S, const nf_keff_opts *o, double *k_coarse, double
     if (!team_is_single(S->team)) return fail(NF_ERR_UNSUPPORTED, "coarse-mesh initialisation is not available on a slab-decomposed mesh");
     HIPCHK(hipSetDevice(S->device));
     bool done = false; double kc = 1.0;
-    if (o->n_coarse_factors > 0) NFCHK(coarse_init(S, o, &kc, S->d_raw, &done));
+    if (o->n_coarse_factors > 0) NFCHK(coarse_init(S->team, o, &kc, { S->d_raw }, &done));
     S->raw_valid = false;
     if (done) std::swap(S->d_raw, S->d_phi);                     // reuse the layout-converting download
     int rc = phi_transfer(S, phi_host, false);
@@ -1009,9 +1028,9 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     double keff = T->has_valid_keff ? T->last_keff : 1.0;        // :1662
     T->coarse_outer = 0;
     if (o->use_coarse_init && o->n_coarse_factors > 0) {          // :1665-1670
-        if (!single) return fail(NF_ERR_UNSUPPORTED, "coarse-mesh initialisation is not available on a slab-decomposed mesh");
         bool done = false; double kc = 1.0;
-        NFCHK(coarse_init(S0, o, &kc, S0->d_phi, &done));
+        std::vector<double *> dsts; for (auto *S : T->slabs) dsts.push_back(S->d_phi);
+        NFCHK(coarse_init(T, o, &kc, dsts, &done));
         keff = done ? kc : 1.0;
     }
     long Ntot = 0; for (auto *S : T->slabs) Ntot += S->nphi;
