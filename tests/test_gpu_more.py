@@ -1,0 +1,82 @@
+"""More GPU parity cases: many groups with up-scatter (SURVEY C5 at a size the oracle handles), one group, natural
+(mirror) boundaries everywhere, re-build with changed cross sections, and the error behaviour of the C ABI."""
+import numpy as np
+import pytest
+
+from helpers import make_hip, make_oracle, rel_l2, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _from_case(c):
+    return dict(x_breaks=c["x_breaks"], y_breaks=c["y_breaks"], z_breaks=c["z_breaks"], D=c["D"], SigR=c["SigR"], NSF=c["NSF"], Chi=c["Chi"],
+                SigS=c["SigS"], bc_attr=np.array([a for a, _ in c["bc"]]), bc_type=np.array([t for _, t in c["bc"]]), ng=c["ng"],
+                coarse_factors=np.array(c["coarse_factors"]))
+
+
+def test_checkerboard_8_groups_with_upscatter():
+    """SURVEY 8d C5 (512^3 x 8 groups, closed-form XS) at 32^3: Gauss-Seidel sweep over 8 groups, 8 scatter blocks"""
+    from neutfem_amd import cases
+    inp = _from_case(cases.synthetic_checkerboard(32, 8))
+    o, s = make_oracle(inp), make_hip(inp)
+    tol = (1e-10, 1e-10, 1e-10, 600, 2000)
+    o.set_tol(*tol); s.set_tol(*tol)
+    ko = o.SolveKeff(True, [2, 2, 2]); ks, n = s.solve_keff(True, [2, 2, 2])
+    assert abs(ks - ko) / ko < 1e-9 and abs(n - o.info("last_outer")) <= 1
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8
+    s.close()
+
+
+@pytest.mark.parametrize("ng,dirichlet", [(1, (1, 2, 3, 4, 5, 6)), (3, ()), (2, (5,))])
+def test_groups_and_natural_boundaries(ng, dirichlet):
+    inp = synthetic_inputs(18, 11, 13, ng, seed=40 + ng, dirichlet=dirichlet)
+    o, s = make_oracle(inp), make_hip(inp)
+    x = np.random.default_rng(1).standard_normal(o.n_phi)
+    assert rel_l2(s.schur_apply(ng - 1, x), o.schur_apply(ng - 1, x)) < 1e-12
+    tol = (1e-10, 1e-10, 1e-10, 1500, 2000)
+    o.set_tol(*tol); s.set_tol(*tol)
+    ko = o.SolveKeff(); ks, _ = s.solve_keff()
+    assert abs(ks - ko) / ko < 1e-9
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8
+    s.close()
+
+
+def test_rebuild_with_changed_xs_keeps_warm_start():
+    """BuildMatrices does not reset has_valid_keff_ / the flux (src/NeutFEM.cpp:454-456 invalidates caches only)"""
+    inp = synthetic_inputs(16, 14, 1, 2, seed=8)
+    o, s = make_oracle(inp), make_hip(inp)
+    tol = (1e-9, 1e-9, 1e-9, 800, 2000)
+    o.set_tol(*tol); s.set_tol(*tol)
+    o.SolveKeff(); s.solve_keff()
+    inp["SigR"] = inp["SigR"] * 1.05
+    o.get_SigR()[...] = inp["SigR"]; o.BuildMatrices()
+    s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"]); s.build()
+    ko = o.SolveKeff(); ks, n = s.solve_keff()
+    assert abs(ks - ko) / ko < 1e-9 and n == o.info("last_outer")
+    assert s.history()["k"][0] == pytest.approx(o.history()["k"][0], rel=1e-8) and s.history()["k"][0] != 1.0   # started from last k
+    s.close()
+
+
+def test_error_behaviour():
+    from neutfem_amd.capi import HipSolver
+    inp = synthetic_inputs(8, 6, 5, 2, seed=1)
+    s = HipSolver(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    with pytest.raises(RuntimeError, match="nf_upload_xs first"):
+        s.build()
+    with pytest.raises(RuntimeError, match="nf_build first"):
+        s.solve_keff()
+    s.upload_xs(inp["D"], inp["SigR"], 0.0 * inp["NSF"], inp["Chi"], inp["SigS"]); s.build()
+    with pytest.raises(RuntimeError, match="diverged"):            # no fission: prod_old = 0 -> k is NaN
+        s.solve_keff()
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        s.schur_apply(7, np.zeros(s.n_phi))
+    s.close()
+    with pytest.raises(RuntimeError, match="out of range"):
+        HipSolver(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], device=99)
+    long_x = np.linspace(0, 1, 1100)
+    t = HipSolver(0, 0, 1, long_x, np.linspace(0, 1, 3), np.array([0.0]))
+    t.upload_xs(np.ones((1, 2, 1099)), np.ones((1, 2, 1099)), np.ones((1, 2, 1099)), np.ones((1, 2, 1099)), np.zeros((1, 1, 2, 1099)))
+    t.build()
+    with pytest.raises(RuntimeError, match="x-line kernel limit"):
+        t.schur_apply(0, np.zeros(t.n_phi))
+    t.close()
