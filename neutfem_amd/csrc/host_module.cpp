@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <fstream>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -170,6 +172,61 @@ public:
         return out;
     }
     std::map<int, int> GetBCMap() const { std::map<int, int> r; for (auto &kv : bc_types_) r[kv.first] = (int)kv.second; return r; }
+
+    // ExportVTK (src/NeutFEM.cpp:2137-2332): legacy ASCII STRUCTURED_GRID, cell data.  Same dataset layout and field
+    // names as the reference so existing ParaView states keep working; written on the host from the host mirrors
+    // (flux, XS) and, for the cell-centred currents, from Sol_J_ fetched through nf_get_J.
+    void ExportVTK(const std::string &filename, bool export_flux, bool export_current, bool export_xs, bool export_adjoint)
+    {
+        const std::string full = filename + ".vtk";
+        std::ofstream f(full);
+        if (!f.is_open()) throw std::runtime_error("Cannot open file: " + full);
+        Log(VerbosityLevel::NORMAL, "Export VTK vers " + full);
+        const long nc = ne_;
+        f << "# vtk DataFile Version 3.0\n" << "NeutFEM Output - k-eff=" << std::fixed << std::setprecision(6) << last_keff_ << "\n"
+          << "ASCII\nDATASET STRUCTURED_GRID\n" << "DIMENSIONS " << nx_ + 1 << " " << ny_ + 1 << " " << nz_ + 1 << "\n"
+          << "POINTS " << (long)(nx_ + 1) * (ny_ + 1) * (nz_ + 1) << " double\n";
+        for (int k = 0; k <= nz_; ++k) for (int j = 0; j <= ny_; ++j) for (int i = 0; i <= nx_; ++i)
+            f << xb_[i] << " " << (dim_ >= 2 ? yb_[j] : 0.0) << " " << (dim_ == 3 ? zb_[k] : 0.0) << "\n";
+        f << "\nCELL_DATA " << nc << "\n";
+        auto scalars = [&](const std::string &name, const std::function<double(long)> &val) {
+            f << "SCALARS " << name << " double 1\nLOOKUP_TABLE default\n";
+            for (long e = 0; e < nc; ++e) f << val(e) << "\n";
+        };
+        if (export_flux) {
+            for (int g = 0; g < ng_; ++g) scalars("Flux_g" + std::to_string(g), [&](long e) { return Phi_[g * nphi_ + e * nloc_]; });
+            scalars("Flux_total", [&](long e) { double t = 0; for (int g = 0; g < ng_; ++g) t += Phi_[g * nphi_ + e * nloc_]; return t; });
+        }
+        (void)export_adjoint;                                     // has_valid_adjoint_ is never true here (adjoint off-path)
+        if (export_current) {
+            if (rt_ != 0) throw std::runtime_error("ExportVTK(export_current=True) needs RT0: currents of RT1/RT2 are not reconstructed on the HIP path");
+            need_built("ExportVTK(export_current=True)");
+            std::vector<double> J((size_t)ng_ * nJ_);
+            chk(nf_get_J(h_, J.data()));
+            const long njx = (long)(nx_ + 1) * ny_ * nz_, njy = dim_ >= 2 ? (long)nx_ * (ny_ + 1) * nz_ : 0;
+            for (int g = 0; g < ng_; ++g) {
+                const double *Jg = J.data() + (size_t)g * nJ_;
+                f << "VECTORS Current_g" << g << " double\n";
+                for (int k = 0; k < nz_; ++k) for (int j = 0; j < ny_; ++j) for (int i = 0; i < nx_; ++i) {
+                    const long fx = ((long)k * ny_ + j) * (nx_ + 1) + i;             // src/FEM.cpp:264-275
+                    double jx = 0.5 * (Jg[fx] + Jg[fx + 1]), jy = 0.0, jz = 0.0;
+                    if (dim_ >= 2) { const long fy = njx + ((long)k * (ny_ + 1) + j) * nx_ + i; jy = 0.5 * (Jg[fy] + Jg[fy + nx_]); }
+                    if (dim_ == 3) { const long fz = njx + njy + ((long)k * ny_ + j) * nx_ + i; jz = 0.5 * (Jg[fz] + Jg[fz + (long)nx_ * ny_]); }
+                    f << jx << " " << jy << " " << jz << "\n";
+                }
+            }
+        }
+        if (export_xs) {
+            const std::pair<const char *, const std::vector<double> *> fields[] = {
+                {"D_g", &D_}, {"SigmaR_g", &SigR_}, {"NuSigF_g", &NSF_}, {"Chi_g", &Chi_}, {"KappaSigF_g", &KSF_}, {"Source_g", &SRC_}};
+            for (auto &fd : fields)
+                for (int g = 0; g < ng_; ++g) scalars(fd.first + std::to_string(g), [&](long e) { return (*fd.second)[g * nc + e]; });
+            for (int gf = 0; gf < ng_; ++gf) for (int gt = 0; gt < ng_; ++gt)
+                scalars("SigS_" + std::to_string(gf) + "_to_" + std::to_string(gt), [&](long e) { return SigS_[((size_t)gt * ng_ + gf) * nc + e]; });
+        }
+        f.close();
+        Log(VerbosityLevel::NORMAL, "  Export termine: " + std::to_string(nc) + " cellules");
+    }
     [[noreturn]] void oos(const char *what, const char *ref) const
     {
         throw std::runtime_error(std::string(what) + " is outside the accelerated hot path of neutfem_amd (reference: " + ref + ")");
@@ -268,10 +325,10 @@ PYBIND11_MODULE(_neutfem_eigen, m)
         .def("SolveCoarse", &NeutFEM::SolveCoarse, py::arg("refine"))
         .def("build_diagonal_cache", &NeutFEM::BuildDiagonalCache)
         .def("initialize_cmfd", [](NeutFEM &s) { s.oos("initialize_cmfd", "src/NeutFEM.cpp:662-760"); })
-        .def("ExportVTK", [](NeutFEM &s, const std::string &, bool, bool, bool, bool) { s.oos("ExportVTK", "src/NeutFEM.cpp:2137-2332"); },
-             py::arg("filename"), py::arg("export_flux") = true, py::arg("export_current") = true, py::arg("export_xs") = false, py::arg("export_adjoint") = false)
-        .def("ExportFluxVTK", [](NeutFEM &s, const std::string &, bool) { s.oos("ExportFluxVTK", "src/NeutFEM.cpp:2324-2327"); }, py::arg("filename"), py::arg("adjoint") = false)
-        .def("ExportXSVTK", [](NeutFEM &s, const std::string &) { s.oos("ExportXSVTK", "src/NeutFEM.cpp:2329-2332"); }, py::arg("filename"))
+        .def("ExportVTK", &NeutFEM::ExportVTK, py::arg("filename"), py::arg("export_flux") = true, py::arg("export_current") = true,
+             py::arg("export_xs") = false, py::arg("export_adjoint") = false)
+        .def("ExportFluxVTK", [](NeutFEM &s, const std::string &fn, bool adj) { s.ExportVTK(fn, true, false, false, adj); }, py::arg("filename"), py::arg("adjoint") = false)
+        .def("ExportXSVTK", [](NeutFEM &s, const std::string &fn) { s.ExportVTK(fn, false, false, true, false); }, py::arg("filename"))
         .def("get_D", [](NeutFEM &s) { return s.view(s.D_); })
         .def("get_SRC", [](NeutFEM &s) { return s.view(s.SRC_); })
         .def("get_SigR", [](NeutFEM &s) { return s.view(s.SigR_); })

@@ -96,3 +96,28 @@ def test_case_generators():
     assert c["D"].shape == (2, 5, 38, 38) and len(c["z_breaks"]) == 6
     k = cases.synthetic_checkerboard(32, 4)
     assert k["SigS"].shape == (4, 4, 32, 32, 32) and k["SigS"][2, 3].max() == 0.002 and k["NSF"][:, 0, 0, 16].max() == 0.0
+
+
+def test_vtk_export_without_gpu(tmp_path):
+    """ExportVTK / ExportFluxVTK / ExportXSVTK (src/NeutFEM.cpp:2137-2332): same legacy-VTK layout and field names"""
+    import neutfem_amd
+    neutfem_amd.install_compat()
+    import neutfem._neutfem_eigen as m
+    s = m.NeutFEM(0, 2, np.linspace(0, 3, 4), np.linspace(0, 2, 3), np.linspace(0, 1, 3))
+    s.set_verbosity(m.VerbosityLevel.SILENT)
+    s.get_D()[1, 1, 0, 2] = 2.5; s.get_SigS()[1, 0, 0, 1, 0] = 0.125
+    base = str(tmp_path / "out")
+    s.ExportVTK(base, export_flux=True, export_current=False, export_xs=True)
+    txt = open(base + ".vtk").read().split("\n")
+    assert txt[0] == "# vtk DataFile Version 3.0" and txt[1] == "NeutFEM Output - k-eff=1.000000" and txt[3] == "DATASET STRUCTURED_GRID"
+    assert txt[4] == "DIMENSIONS 4 3 3" and txt[5] == "POINTS 36 double" and "CELL_DATA 12" in txt
+    for name in ["Flux_g0", "Flux_g1", "Flux_total", "D_g1", "SigmaR_g0", "NuSigF_g1", "Chi_g0", "KappaSigF_g0", "Source_g1", "SigS_0_to_1", "SigS_1_to_0"]:
+        assert f"SCALARS {name} double 1" in txt, name
+    i = txt.index("SCALARS D_g1 double 1"); vals = [float(v) for v in txt[i + 2:i + 14]]
+    assert vals[6 + 0 * 3 + 2] == 2.5 and sum(vals) == 11 + 2.5            # cell (iz=1, iy=0, ix=2)
+    i = txt.index("SCALARS SigS_0_to_1 double 1"); assert float(txt[i + 2 + 3]) == 0.125     # cell (0,1,0)
+    i = txt.index("SCALARS Flux_total double 1"); assert float(txt[i + 2]) == 2.0
+    s.ExportFluxVTK(base + "_f"); s.ExportXSVTK(base + "_x")
+    assert "SCALARS D_g0 double 1" not in open(base + "_f.vtk").read() and "Flux_g0" not in open(base + "_x.vtk").read()
+    with pytest.raises(RuntimeError):
+        s.ExportVTK(base, True, True, False, False)                        # currents need a built GPU solver

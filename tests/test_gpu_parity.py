@@ -197,3 +197,34 @@ def test_pybind_module_end_to_end():
     assert m.GetLastKeff() == k
     with pytest.raises(RuntimeError):
         m.SolveAdjoint()
+
+
+def test_vtk_export_currents(tmp_path):
+    """cell-centred currents in the VTK file = face averages of the oracle's Sol_J_ (src/NeutFEM.cpp:2215-2246)"""
+    import neutfem_amd
+    neutfem_amd.install_compat()
+    import neutfem._neutfem_eigen as ns
+    inp = synthetic_inputs(7, 6, 5, 2, seed=12)
+    o = make_oracle(inp)
+    m = ns.NeutFEM(0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    m.set_verbosity(ns.VerbosityLevel.SILENT); m.set_linear_solver(ns.LinearSolverType.BICGSTAB)
+    for a in inp["bc_attr"]:
+        m.set_bc(int(a), ns.BCType.DIRICHLET, 0.0)
+    m.get_D()[...] = inp["D"]; m.get_SigR()[...] = inp["SigR"]; m.get_NSF()[...] = inp["NSF"]; m.get_Chi()[...] = inp["Chi"]; m.get_SigS()[...] = inp["SigS"]
+    m.BuildMatrices()
+    tol = (1e-10, 1e-10, 1e-10, 800, 2000)
+    m.set_tol(*tol); o.set_tol(*tol)
+    k = m.SolveKeff(); ko = o.SolveKeff()
+    m.ExportVTK(str(tmp_path / "c"), export_flux=True, export_current=True, export_xs=False)
+    txt = open(str(tmp_path / "c.vtk")).read().split("\n")
+    assert txt[1] == f"NeutFEM Output - k-eff={k:.6f}"
+    i = txt.index("VECTORS Current_g1 double")
+    got = np.array([[float(v) for v in line.split()] for line in txt[i + 1:i + 1 + 210]])
+    J = o.J_dofs()[1]; nx, ny, nz = 7, 6, 5; njx = (nx + 1) * ny * nz; njy = nx * (ny + 1) * nz
+    exp = np.zeros((nz, ny, nx, 3))
+    for kz in range(nz):
+        for j in range(ny):
+            for i_ in range(nx):
+                fx = (kz * ny + j) * (nx + 1) + i_; fy = njx + (kz * (ny + 1) + j) * nx + i_; fz = njx + njy + (kz * ny + j) * nx + i_
+                exp[kz, j, i_] = [0.5 * (J[fx] + J[fx + 1]), 0.5 * (J[fy] + J[fy + nx]), 0.5 * (J[fz] + J[fz + nx * ny])]
+    assert np.abs(got - exp.reshape(-1, 3)).max() <= 1e-6 * max(1.0, np.abs(exp).max())      # file holds 6 decimals
