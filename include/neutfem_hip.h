@@ -107,6 +107,11 @@ typedef struct nf_keff_opts {
  * current flux (nf_set_phi/nf_get_phi) and has_valid_keff_/last_keff_direct_. */
 int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_outer);
 
+/* NeutFEM::SolveAdjoint(normalize_to_direct, use_direct_keff) (src/NeutFEM.cpp:1877-2082, BuildFissionRHSAdjoint
+ * :1568-1589): tolerances / solver type from opts; the adjoint flux is fetched with nf_get_phi_adj (host layout of phi). */
+int nf_solve_adjoint(nf_handle h, const nf_keff_opts *opts, int normalize_to_direct, int use_direct_keff, double *keff_adj, int *n_outer);
+int nf_get_phi_adj(nf_handle h, double *phi_adj_host);
+
 /* NeutFEM::SolveCoarse (src/NeutFEM.cpp:2380-2611): returns k_coarse and the prolonged flux
  * (ng*n_phi doubles, host) without touching the fine solution. */
 int nf_solve_coarse(nf_handle h, const nf_keff_opts *opts, double *k_coarse, double *phi_host);

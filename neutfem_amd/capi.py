@@ -14,7 +14,7 @@ SYMBOLS = [
     "nf_last_error", "nf_device_count", "nf_create", "nf_destroy", "nf_create_slab", "nf_link_slabs", "nf_comm_unique_id",
     "nf_comm_init", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
-    "nf_solve_coarse", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
+    "nf_solve_coarse", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply",
     "nf_set_option", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
@@ -59,6 +59,8 @@ def load():
     L.nf_get_diagonal_cache.argtypes = [vp, C.c_int, dp]
     L.nf_solve_keff.argtypes = [vp, C.POINTER(KeffOpts), dp, ip]
     L.nf_solve_coarse.argtypes = [vp, C.POINTER(KeffOpts), dp, dp]
+    L.nf_solve_adjoint.argtypes = [vp, C.POINTER(KeffOpts), C.c_int, C.c_int, dp, ip]
+    L.nf_get_phi_adj.argtypes = [vp, dp]
     L.nf_set_phi.argtypes = [vp, dp]
     L.nf_get_phi.argtypes = [vp, dp]
     L.nf_get_J.argtypes = [vp, dp]
@@ -198,6 +200,15 @@ class HipSolver:
         k = C.c_double(); out = np.empty(self.ng * self.n_phi)
         self._chk(self.L.nf_solve_coarse(self.h, C.byref(o), C.byref(k), _dp(out)))
         return k.value, out
+
+    def solve_adjoint(self, normalize_to_direct=True, use_direct_keff=True):
+        o = self.opts()
+        k, n = C.c_double(), C.c_int()
+        self._chk(self.L.nf_solve_adjoint(self.h, C.byref(o), int(normalize_to_direct), int(use_direct_keff), C.byref(k), C.byref(n)))
+        return k.value, n.value
+
+    def get_phi_adj(self):
+        out = np.empty(self.ng * self.n_phi); self._chk(self.L.nf_get_phi_adj(self.h, _dp(out))); return out.reshape(self.ng, self.n_phi)
 
     def diagonal_cache(self, g):
         out = np.empty(self.ne)

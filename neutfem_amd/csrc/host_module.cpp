@@ -163,6 +163,20 @@ public:
         chk(nf_solve_coarse(h_, &o, &k, out.mutable_data()));
         return {k, out};
     }
+    double SolveAdjoint(bool normalize_to_direct, bool use_direct_keff)
+    {
+        need_built("SolveAdjoint");
+        Log(VerbosityLevel::NORMAL, "\n=== CALCUL DE K-EFFECTIF (ADJOINT) ===");
+        chk(nf_set_phi(h_, Phi_.data()));                         // the bi-orthonormalisation uses the direct flux
+        chk(nf_set_warm_state(h_, has_valid_keff_ ? 1 : 0, last_keff_));
+        nf_keff_opts o = make_opts(false, {}, false);
+        double k = 1.0; int nout = 0;
+        chk(nf_solve_adjoint(h_, &o, normalize_to_direct ? 1 : 0, use_direct_keff ? 1 : 0, &k, &nout));
+        chk(nf_get_phi_adj(h_, PhiAdj_.data()));
+        if (verb_ >= VerbosityLevel::NORMAL) std::cout << "  k-eff adjoint = " << std::fixed << std::setprecision(8) << k << std::defaultfloat << std::endl;
+        last_keff_adj_ = k;
+        return k;
+    }
     void BuildDiagonalCache() { need_built("build_diagonal_cache"); chk(nf_build_diagonal_cache(h_)); }
     py::array_t<double> GetCurrent()
     {
@@ -319,8 +333,7 @@ PYBIND11_MODULE(_neutfem_eigen, m)
         .def("BuildMatrices", &NeutFEM::BuildMatrices)
         .def("SolveKeff", &NeutFEM::SolveKeff, py::arg("use_coarse_init") = false, py::arg("coarse_factors") = std::vector<int>{},
              py::arg("use_diagonal_solver") = false, py::arg("use_cmfd") = false)
-        .def("SolveAdjoint", [](NeutFEM &s, bool, bool) -> double { s.oos("SolveAdjoint", "src/NeutFEM.cpp:1877-2082"); },
-             py::arg("normalize_to_direct") = true, py::arg("use_direct_keff") = true)
+        .def("SolveAdjoint", &NeutFEM::SolveAdjoint, py::arg("normalize_to_direct") = true, py::arg("use_direct_keff") = true)
         .def("SolveSubcritical", [](NeutFEM &s) { s.oos("SolveSubcritical", "declared at include/NeutFEM.hpp:279, never defined"); })
         .def("SolveCoarse", &NeutFEM::SolveCoarse, py::arg("refine"))
         .def("build_diagonal_cache", &NeutFEM::BuildDiagonalCache)

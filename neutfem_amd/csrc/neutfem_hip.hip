@@ -121,7 +121,9 @@ struct nf_solver {
     std::vector<double *> d_SigS;          // ng*ng blocks [g_to*ng+g_from], nullptr when all |s| <= 1e-14
     bool xs_uploaded = false, built = false, diag_valid = false;
     // operators
-    double *d_Cd = nullptr, *d_Mf = nullptr;            // ng*N
+    double *d_Cd = nullptr, *d_Mf = nullptr, *d_Mchi = nullptr;   // ng*nphi diagonals: C, fission, chi-weighted mass (adjoint)
+    double *d_phi_adj = nullptr;                        // adjoint flux, ng*nphi (allocated by the first adjoint solve)
+    int has_valid_adjoint = 0; double last_keff_adj = 1.0;
     std::vector<double *> d_Ms;                          // ng*ng
     double *d_L[3] = {nullptr, nullptr, nullptr}, *d_DR[3] = {nullptr, nullptr, nullptr}, *d_D0[3] = {nullptr, nullptr, nullptr};
     long nlines[3] = {0, 0, 0};
@@ -339,7 +341,7 @@ int nf_destroy(nf_handle S)
     dfree(S->d_D); dfree(S->d_SigR); dfree(S->d_NSF); dfree(S->d_Chi);
     for (auto &p : S->d_SigS) dfree(p);
     for (auto &p : S->d_Ms) dfree(p);
-    dfree(S->d_Cd); dfree(S->d_Mf); dfree(S->d_Sinv);
+    dfree(S->d_Cd); dfree(S->d_Mf); dfree(S->d_Mchi); dfree(S->d_phi_adj); dfree(S->d_Sinv);
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
@@ -452,7 +454,7 @@ int nf_build(nf_handle S)
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const int ng = S->ng; const long N = S->N, NP = S->nphi; const size_t NN = (size_t)N * ng;
-    NFCHK(dalloc(&S->d_Cd, (size_t)NP * ng)); NFCHK(dalloc(&S->d_Mf, (size_t)NP * ng));
+    NFCHK(dalloc(&S->d_Cd, (size_t)NP * ng)); NFCHK(dalloc(&S->d_Mf, (size_t)NP * ng)); NFCHK(dalloc(&S->d_Mchi, (size_t)NP * ng));
     for (int d = 0; d < S->dim; ++d) {
         NFCHK(dalloc(&S->d_L[d], NN)); NFCHK(dalloc(&S->d_DR[d], NN)); NFCHK(dalloc(&S->d_D0[d], (size_t)S->nlines[d] * ng));
     }
@@ -473,6 +475,7 @@ int nf_build(nf_handle S)
     for (int g = 0; g < ng; ++g) {
         hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_SigR + g * N, S->d_Cd + g * NP, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 0, S->dim, ch);
         hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_NSF + g * N, S->d_Mf + g * NP, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 1, S->dim, ch);
+        hipLaunchKernelGGL(k_cell_coef, dim3(gN), dim3(256), 0, st, S->d_Chi + g * N, S->d_Mchi + g * NP, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 2, S->dim, ch);   // M_chi (:432-439)
         for (int gp = 0; gp < ng; ++gp) {
             const int i = g * ng + gp;
             if (!S->d_SigS[i]) { dfree(S->d_Ms[i]); continue; }
@@ -851,22 +854,23 @@ int nf_get_diagonal_cache(nf_handle S, int g, double *sinv_host)
 
 // ---- state -------------------------------------------------------------------------------------
 // host layout [g][e*nloc + p] (reference, src/FEM.cpp:321-334) <-> device layout [g][p][e]
-static int phi_transfer(nf_solver *S, double *host, bool to_device)
+static int phi_transfer(nf_solver *S, double *host, bool to_device, double *dev = nullptr)
 {
+    if (!dev) dev = S->d_phi;
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     HIPCHK(hipStreamSynchronize(st));
     const size_t NN = (size_t)S->nphi * S->ng;
     if (S->nloc == 1) {
-        if (to_device) HIPCHK(hipMemcpy(S->d_phi, host, NN * sizeof(double), hipMemcpyHostToDevice));
-        else HIPCHK(hipMemcpy(host, S->d_phi, NN * sizeof(double), hipMemcpyDeviceToHost));
+        if (to_device) HIPCHK(hipMemcpy(dev, host, NN * sizeof(double), hipMemcpyHostToDevice));
+        else HIPCHK(hipMemcpy(host, dev, NN * sizeof(double), hipMemcpyDeviceToHost));
         return NF_OK;
     }
     double *tmp = nullptr; NFCHK(dalloc(&tmp, NN));
     if (to_device) HIPCHK(hipMemcpy(tmp, host, NN * sizeof(double), hipMemcpyHostToDevice));
     for (int g = 0; g < S->ng; ++g) {
-        const double *src = (to_device ? tmp : S->d_phi) + (size_t)g * S->nphi;
-        double *dst = (to_device ? S->d_phi : tmp) + (size_t)g * S->nphi;
+        const double *src = (to_device ? tmp : dev) + (size_t)g * S->nphi;
+        double *dst = (to_device ? dev : tmp) + (size_t)g * S->nphi;
         hipLaunchKernelGGL(k_transpose_dofs, dim3(grid_for(S->nphi)), dim3(256), 0, st, src, dst, S->N, S->nloc, to_device ? 1 : 0);
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -1056,7 +1060,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         // total_fiss and prod_old (:1700-1707)
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
-            hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_phi, ng, S->nphi, S->d_tf, T->d_partials + i * T->slab_cap);
+            hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_phi, ng, S->nphi, S->d_tf, T->d_partials + i * T->slab_cap, (const double *)nullptr, 0L);
         }
         NFCHK(team_finalize(T, FIN_SUM, gN, 1, T->d_out, 0.0, 0));
         for (int g = 0; g < ng; ++g) {
@@ -1124,6 +1128,117 @@ int nf_solve_keff(nf_handle S, const nf_keff_opts *o, double *keff, int *n_outer
     for (auto *X : S->team->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_solve_keff: call nf_build first");
     HIPCHK(hipSetDevice(S->device));
     return solve_keff_impl(S->team, o, keff, n_outer);
+}
+
+// ---- SolveAdjoint (src/NeutFEM.cpp:1877-2082) -----------------------------------------------------
+// Literal control flow of the reference, including what makes it fragile (forward-ordered sweep on the transposed scatter,
+// Chebyshev from outer 5 when k is free).  Undivided meshes only.
+int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct, int use_direct_keff, double *keff_adj, int *n_outer)
+{
+    if (!S || !o) return fail(NF_ERR_ARG, "nf_solve_adjoint: bad arguments");
+    if (!S->built) return fail(NF_ERR_STATE, "nf_solve_adjoint: call nf_build first");
+    nf_team *T = S->team;
+    if (!team_is_single(T)) return fail(NF_ERR_UNSUPPORTED, "the adjoint solve is not available on a slab-decomposed mesh");
+    HIPCHK(hipSetDevice(S->device));
+    const int ng = S->ng; const long N = S->N, NP = S->nphi, NT = NP * ng;
+    const int G = grid_for(NP), GT = grid_for(NT);
+    hipStream_t st = T->stream;
+    double keff = 1.0;
+    if (use_direct_keff && T->has_valid_keff) keff = T->last_keff;          // :1885-1889
+    if (!S->d_phi_adj) NFCHK(dalloc(&S->d_phi_adj, (size_t)NT));
+    hipLaunchKernelGGL(k_fill_const, dim3(GT), dim3(256), 0, st, S->d_phi_adj, NT, 1.0 / std::sqrt((double)NT));   // 1 / ||1||  (:1891-1892)
+    double *d_nsft = nullptr; NFCHK(dalloc(&d_nsft, (size_t)N));
+    hipLaunchKernelGGL(k_sum_groups, dim3(grid_for(N)), dim3(256), 0, st, S->d_NSF, d_nsft, N, ng);                  // :1898-1905
+    const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || NP < 200;
+    const double cg_tol = direct ? 1e-14 : o->tol_flux;
+    const int cg_max = direct ? (int)std::min<long>(20 * NP + 50, 2000000000L) : o->max_inner;
+    const int nmax = 15; const double sigma = 0.98;
+    double ca[16], cbv[16];
+    { const double Gm = std::acosh(2. / sigma - 1.); ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
+      for (int i = 2; i < nmax; ++i) { ca[i] = std::cosh((i - 1) * Gm) / std::cosh(i * Gm); cbv[i] = std::cosh((i - 2) * Gm) / std::cosh(i * Gm); } }
+    int cheb_it = 0;
+    T->hist_k.clear(); T->hist_dk.clear(); T->hist_dphi.clear(); T->hist_cg.clear();
+    T->last_outer = 0; T->last_cg_total = 0;
+    ScatterArgs sa; sa.ng = ng;
+    double hout[4];
+    const std::vector<int> cG = { G }, cGT = { GT };
+    int rc = NF_OK;
+    for (int it = 0; it < o->max_outer && rc == NF_OK; ++it) {
+        // total_chi_adj and prod_old = sum_e nsf_tot[e] * tca[e, dof 0]   (:1912-1936)
+        hipLaunchKernelGGL(k_fission, dim3(G), dim3(256), 0, st, S->d_Mchi, S->d_phi_adj, ng, NP, S->d_tf, T->d_partials, (const double *)d_nsft, N);
+        if ((rc = team_finalize(T, FIN_SUM, cG, 1, T->d_out, 0.0, 0)) != NF_OK) break;
+        for (int g = 0; g < ng && rc == NF_OK; ++g) {
+            for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[gp * ng + g] : nullptr;           // transposed blocks (:1944-1950)
+            hipLaunchKernelGGL(k_group_rhs, dim3(G), dim3(256), 0, st, sa, g, S->d_NSF + g * N, S->d_tf, 1.0 / keff, S->d_raw, S->d_phi_adj,
+                               (const double *)nullptr, S->d_rhs, NP, N);
+            int its = 0;
+            rc = cg_solve(T, g, { S->d_rhs }, { S->d_raw + g * NP }, cg_tol, cg_max, &its, nullptr);
+            T->hist_cg.push_back(its); T->last_cg_total += its;
+        }
+        if (rc != NF_OK) break;
+        hipLaunchKernelGGL(k_fission, dim3(G), dim3(256), 0, st, S->d_Mchi, S->d_raw, ng, NP, S->d_tf, T->d_partials, (const double *)d_nsft, N);
+        if ((rc = team_finalize(T, FIN_SUM, cG, 1, T->d_out + 1, 0.0, 0)) != NF_OK) break;
+        hipLaunchKernelGGL(k_outer_reduce, dim3(GT), dim3(256), 0, st, S->d_Mchi, S->d_raw, S->d_phi_adj, NT, T->d_partials, T->partial_stride);
+        if ((rc = team_finalize(T, FIN_SUM, cGT, 3, T->d_red, 0.0, 0)) != NF_OK) break;        // d_red: { unused, ||phi||^2, ||dphi||^2 }
+        double hred[3];
+        if (hipMemcpyAsync(hout, T->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(hred, T->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = fail(NF_ERR_HIP, "adjoint: read-back failed"); break; }
+        const double prod_old = hout[0], prod_new = hout[1], nsq = hred[1], dsq = hred[2];
+        double keff_new = keff, dk;
+        if (!use_direct_keff || !T->has_valid_keff) {                          // :1966-1975
+            if (std::fabs(prod_old) > 1e-14 && it > 0) keff_new = keff * (prod_new / prod_old);
+            dk = std::fabs(keff_new - keff); keff = keff_new;
+        } else dk = 0.0;
+        const double dphi = std::sqrt(dsq) / std::sqrt(nsq), norm = std::sqrt(nsq);
+        if (!std::isfinite(keff) || !std::isfinite(dphi)) { rc = fail(NF_ERR_NUMERIC, "adjoint iteration diverged (outer %d: k=%g dphi=%g)", it, keff, dphi); break; }
+        int mode = 0; double a = 0.0, b = 0.0;
+        if (!use_direct_keff && it >= 5) {                                     // :1990-1992
+            if (cheb_it == nmax) cheb_it = 0;
+            if (cheb_it == 0) mode = 1; else if (cheb_it == 1) { mode = 2; a = ca[1]; } else { mode = 3; a = (4. / sigma) * ca[cheb_it]; b = cbv[cheb_it]; }
+            if (!S->d_p0) { if ((rc = dalloc(&S->d_p0, (size_t)NT)) != NF_OK || (rc = dalloc(&S->d_p1, (size_t)NT)) != NF_OK) break; }
+            ++cheb_it;
+        }
+        hipLaunchKernelGGL(k_normalize_cheb, dim3(GT), dim3(256), 0, st, S->d_raw, S->d_phi_adj, S->d_p0, S->d_p1, NT, norm, norm > 1e-14 ? 1 : 0, mode, a, b);
+        if (mode == 3) std::swap(S->d_p0, S->d_p1);
+        T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
+        T->last_outer = it + 1;
+        bool conv = dphi < o->tol_flux;
+        if (!use_direct_keff) conv = conv && dk < o->tol_keff;
+        if (conv) break;
+    }
+    if (rc == NF_OK && normalize_to_direct && T->has_valid_keff) {            // <phi, phi+> = 1 with vol * w = detJ * C-hat_pp (:2020-2066)
+        double *d_mass = nullptr, *d_one = nullptr;
+        rc = dalloc(&d_mass, (size_t)NP); if (rc == NF_OK) rc = dalloc(&d_one, (size_t)N);
+        if (rc == NF_OK) {
+            ChatArgs ch; ch.nloc = S->nloc;
+            for (int p = 0; p < S->nloc; ++p) { int q = p; double c = 1.0; for (int t = 0; t < S->dim; ++t) { c *= 2.0 / (2.0 * (q % S->n1) + 1.0); q /= S->n1; } ch.c[p] = c; }
+            hipLaunchKernelGGL(k_fill_const, dim3(grid_for(N)), dim3(256), 0, st, d_one, N, 1.0);
+            hipLaunchKernelGGL(k_cell_coef, dim3(grid_for(N, 256, 65535)), dim3(256), 0, st, d_one, d_mass, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 2, S->dim, ch);
+            hipLaunchKernelGGL(k_dot3, dim3(GT), dim3(256), 0, st, S->d_phi, S->d_phi_adj, d_mass, NP, ng, T->d_partials);
+            rc = team_finalize(T, FIN_SUM, cGT, 1, T->d_out, 0.0, 0);
+            double ip = 0.0;
+            if (rc == NF_OK && (hipMemcpyAsync(&ip, T->d_out, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+                rc = fail(NF_ERR_HIP, "adjoint: read-back failed");
+            if (rc == NF_OK && std::fabs(ip) > 1e-14) hipLaunchKernelGGL(k_scale, dim3(GT), dim3(256), 0, st, S->d_phi_adj, NT, ip);
+        }
+        dfree(d_mass); dfree(d_one);
+    }
+    (void)hipStreamSynchronize(st);
+    dfree(d_nsft);
+    if (rc != NF_OK) return rc;
+    HIPCHK(hipGetLastError());
+    S->raw_valid = false;
+    S->has_valid_adjoint = 1; S->last_keff_adj = keff;
+    if (keff_adj) *keff_adj = keff;
+    if (n_outer) *n_outer = T->last_outer;
+    return NF_OK;
+}
+int nf_get_phi_adj(nf_handle S, double *phi_host)
+{
+    if (!S || !phi_host) return fail(NF_ERR_ARG, "nf_get_phi_adj: bad arguments");
+    if (!S->d_phi_adj) { for (long i = 0; i < S->nphi * S->ng; ++i) phi_host[i] = 1.0; return NF_OK; }   // Sol_Phi_adj_ = 1 (:226-235)
+    return phi_transfer(S, phi_host, false, S->d_phi_adj);
 }
 
 int nf_get_history(nf_handle S, double *k, double *dk, double *dphi, int *cg, int cap)

@@ -120,7 +120,7 @@ __global__ void k_cell_coef(const double *__restrict__ xs, double *__restrict__ 
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
         const int ix = (int)(e % nx); const long r = e / nx; const int iy = (int)(r % ny); const int iz = (int)(r / ny);
         const double s = xs[e];
-        if (ch.nloc == 1) {
+        if (ch.nloc == 1 && mode != 2) {
             const double V = hx[ix] * hy[iy] * hz[iz];
             double v = s * V;
             if (mode == 0) { if (!(fabs(v) > 1e-14)) v = 0.0; }
@@ -130,7 +130,7 @@ __global__ void k_cell_coef(const double *__restrict__ xs, double *__restrict__ 
             double detJ = hx[ix] / 2.0;
             if (dim >= 2) detJ *= hy[iy] / 2.0;
             if (dim == 3) detJ *= hz[iz] / 2.0;
-            const bool skip = mode == 1 && fabs(s) < 1e-14;
+            const bool skip = mode >= 1 && fabs(s) < 1e-14;      // mode 2: AssembleWeightedMassMatrix (:1495-1529), any order
             for (int p = 0; p < ch.nloc; ++p) {
                 double v = skip ? 0.0 : s * detJ * ch.c[p];
                 if (!(fabs(v) > 1e-14)) v = 0.0;
@@ -661,15 +661,18 @@ __global__ __launch_bounds__(256) void k_cg_pupdate(double *__restrict__ p, cons
 // ---------------------------------------------------------------------------------------------
 // power iteration kernels (src/NeutFEM.cpp:1694-1788)
 // total_fiss = sum_g M_fiss[g] phi_g ; partial sum of entries (prod_old)        (:1700-1707)
+// With w != NULL (adjoint, :1930-1936) the partial sum is sum_{e < nw} w[e] * tf[e] (DOF 0 of every cell = first N entries).
 __global__ __launch_bounds__(256) void k_fission(const double *__restrict__ Mf, const double *__restrict__ phi, int ng,
-                                                 long n, double *__restrict__ tf, double *__restrict__ partials)
+                                                 long n, double *__restrict__ tf, double *__restrict__ partials,
+                                                 const double *__restrict__ w, long nw)
 {
     __shared__ double sred[4];
     double s = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
         double v = 0.0;
         for (int g = 0; g < ng; ++g) v += Mf[g * n + i] * phi[g * n + i];
-        tf[i] = v; s += v;
+        tf[i] = v;
+        if (!w) s += v; else if (i < nw) s += w[i] * v;
     }
     s = block_sum(s, sred);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -728,6 +731,30 @@ __global__ __launch_bounds__(256) void k_normalize_cheb(const double *__restrict
         }
         cur[i] = v;
     }
+}
+
+// adjoint helpers: sum over groups, weighted dot product, scaling
+__global__ void k_sum_groups(const double *__restrict__ a, double *__restrict__ out, long n, int ng)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) { double v = 0.0; for (int g = 0; g < ng; ++g) v += a[g * n + i]; out[i] = v; }
+}
+// partial sums of sum_g sum_i a[g][i] b[g][i] m[i]   (bi-orthonormalisation <phi, phi+>, :2020-2066)
+__global__ __launch_bounds__(256) void k_dot3(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ m,
+                                              long n, int ng, double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n * ng; i += gridDim.x * 256L) s += a[i] * b[i] * m[i % n];
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ void k_scale(double *__restrict__ v, long n, double divisor)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) v[i] /= divisor;
+}
+__global__ void k_fill_const(double *__restrict__ v, long n, double c)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) v[i] = c;
 }
 
 // SolveCoarse: arithmetic volume-weighted block means (src/NeutFEM.cpp:2494-2556), one thread per coarse cell
