@@ -15,15 +15,15 @@ def _from_case(c):
 
 
 def test_checkerboard_8_groups_with_upscatter():
-    """SURVEY 8d C5 (512^3 x 8 groups, closed-form XS) at 32^3: Gauss-Seidel sweep over 8 groups, 8 scatter blocks"""
+    """SURVEY 8d C5 (512^3 x 8 groups, closed-form XS) at 24^3: Gauss-Seidel sweep over 8 groups, 8 scatter blocks"""
     from neutfem_amd import cases
-    inp = _from_case(cases.synthetic_checkerboard(32, 8))
+    inp = _from_case(cases.synthetic_checkerboard(24, 8))
     o, s = make_oracle(inp), make_hip(inp)
-    tol = (1e-10, 1e-10, 1e-10, 600, 2000)
+    tol = (1e-9, 1e-9, 1e-9, 600, 2000)
     o.set_tol(*tol); s.set_tol(*tol)
     ko = o.SolveKeff(True, [2, 2, 2]); ks, n = s.solve_keff(True, [2, 2, 2])
     assert abs(ks - ko) / ko < 1e-9 and abs(n - o.info("last_outer")) <= 1
-    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 5e-8
     s.close()
 
 

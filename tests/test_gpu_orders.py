@@ -41,7 +41,7 @@ def test_solve_keff_golden_higher_order(name, rt, p):
     s.close()
 
 
-@pytest.mark.parametrize("rt,p,shape", [(1, 1, (10, 9, 8)), (2, 2, (7, 6, 5)), (2, 1, (20, 14, 1)), (1, 1, (40, 1, 1))])
+@pytest.mark.parametrize("rt,p,shape", [(1, 1, (8, 7, 6)), (2, 2, (5, 4, 4)), (2, 1, (20, 14, 1)), (1, 1, (40, 1, 1))])
 def test_solve_keff_orders_vs_oracle(rt, p, shape):
     inp = synthetic_inputs(*shape, ng=2, seed=5 + rt + p)
     tol = (1e-11, 1e-11, 1e-11, 1500, 3000)

@@ -48,7 +48,7 @@ def test_thin_middle_slab_is_refused():
 
 @pytest.mark.parametrize("planes", [[(0, 48), (48, 96)], [(0, 32), (32, 64), (64, 96)]])
 def test_team_solve_keff_matches_undivided_and_oracle(planes):
-    inp = synthetic_inputs(10, 8, 96, 2, seed=9)
+    inp = synthetic_inputs(8, 6, 96, 2, seed=9)
     tol = (1e-10, 1e-10, 1e-10, 1000, 2000)
     o, s, t = make_oracle(inp), make_hip(inp), make_team(inp, planes)
     o.set_tol(*tol); s.set_tol(*tol); t.set_tol(*tol)
@@ -84,10 +84,10 @@ def test_rccl_allreduce_path_single_rank(monkeypatch):
     through ncclAllReduce on the solver's stream (what one cannot test here is ncclSend/ncclRecv between ranks)."""
     from neutfem_amd.capi import HipTeam
     monkeypatch.setenv("NEUTFEM_FORCE_RCCL", "1")
-    inp = synthetic_inputs(16, 12, 80, 2, seed=3)
+    inp = synthetic_inputs(12, 8, 80, 2, seed=3)
     s, t = make_hip(inp), make_team(inp, [(0, 40), (40, 80)])
     t.comm_init(HipTeam.unique_id(), 1, 0)
-    tol = (1e-10, 1e-10, 1e-10, 500, 2000)
+    tol = (1e-9, 1e-9, 1e-9, 500, 2000)
     s.set_tol(*tol); t.set_tol(*tol)
     ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
     assert abs(kt - ks) / ks < 1e-10 and abs(nt - ns) <= 1
