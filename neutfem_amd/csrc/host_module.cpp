@@ -213,19 +213,19 @@ public:
         }
         (void)export_adjoint;                                     // has_valid_adjoint_ is never true here (adjoint off-path)
         if (export_current) {
-            if (rt_ != 0) throw std::runtime_error("ExportVTK(export_current=True) needs RT0: currents of RT1/RT2 are not reconstructed on the HIP path");
             need_built("ExportVTK(export_current=True)");
             std::vector<double> J((size_t)ng_ * nJ_);
             chk(nf_get_J(h_, J.data()));
-            const long njx = (long)(nx_ + 1) * ny_ * nz_, njy = dim_ >= 2 ? (long)nx_ * (ny_ + 1) * nz_ : 0;
+            int nf = 1; for (int t = 1; t < dim_; ++t) nf *= rt_ + 1;          // first DOF of every face (JxFaceIndex(..., local_dof = 0))
+            const long njx = (long)(nx_ + 1) * ny_ * nz_ * nf, njy = dim_ >= 2 ? (long)nx_ * (ny_ + 1) * nz_ * nf : 0;
             for (int g = 0; g < ng_; ++g) {
                 const double *Jg = J.data() + (size_t)g * nJ_;
                 f << "VECTORS Current_g" << g << " double\n";
                 for (int k = 0; k < nz_; ++k) for (int j = 0; j < ny_; ++j) for (int i = 0; i < nx_; ++i) {
                     const long fx = ((long)k * ny_ + j) * (nx_ + 1) + i;             // src/FEM.cpp:264-275
-                    double jx = 0.5 * (Jg[fx] + Jg[fx + 1]), jy = 0.0, jz = 0.0;
-                    if (dim_ >= 2) { const long fy = njx + ((long)k * (ny_ + 1) + j) * nx_ + i; jy = 0.5 * (Jg[fy] + Jg[fy + nx_]); }
-                    if (dim_ == 3) { const long fz = njx + njy + ((long)k * ny_ + j) * nx_ + i; jz = 0.5 * (Jg[fz] + Jg[fz + (long)nx_ * ny_]); }
+                    double jx = 0.5 * (Jg[fx * nf] + Jg[(fx + 1) * nf]), jy = 0.0, jz = 0.0;
+                    if (dim_ >= 2) { const long fy = ((long)k * (ny_ + 1) + j) * nx_ + i; jy = 0.5 * (Jg[njx + fy * nf] + Jg[njx + (fy + nx_) * nf]); }
+                    if (dim_ == 3) { const long fz = ((long)k * ny_ + j) * nx_ + i; jz = 0.5 * (Jg[njx + njy + fz * nf] + Jg[njx + njy + (fz + (long)nx_ * ny_) * nf]); }
                     f << jx << " " << jy << " " << jz << "\n";
                 }
             }

@@ -904,19 +904,27 @@ int nf_get_J(nf_handle S, double *J_host)
 {
     if (!S || !J_host) return fail(NF_ERR_ARG, "nf_get_J: bad arguments");
     if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "nf_get_J is not available on a slab (currents are reconstructed on undivided meshes only)");
-    if (S->k != 0) return fail(NF_ERR_UNSUPPORTED, "nf_get_J is implemented for RT0 only (RT%d asked)", S->k);
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const long N = S->N, nJ = S->nJ;
     if (!S->raw_valid) { memset(J_host, 0, sizeof(double) * nJ * S->ng); return NF_OK; }   // Sol_J_ = 0 before any solve
     double *dJ = nullptr; NFCHK(dalloc(&dJ, (size_t)nJ));
     Geom G = make_geom(S);
-    const long off[3] = { 0, S->nJx, S->nJx + S->nJy };
+    int nfa = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nfa *= S->k + 1; ni *= S->k + 1; }
+    const long nJface = S->nJx + S->nJy + S->nJz;
+    const long foff[3] = { 0, S->nJx, S->nJx + S->nJy };
     for (int g = 0; g < S->ng; ++g) {
+        HIPCHK(hipMemsetAsync(dJ, 0, (size_t)nJ * sizeof(double), st));                     // modes that see no phi moment stay 0
         for (int d = 0; d < S->dim; ++d)
-            hipLaunchKernelGGL(k_flux_to_J, dim3((unsigned)((S->nlines[d] + 63) / 64)), dim3(64), 0, st, G, d, S->d_D + g * N,
-                               S->d_raw + g * N, S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * S->nlines[d], dJ + off[d],
-                               S->nlines[d], S->raw_is_diag ? 1 : 0);
+            for (int mode = 0; mode < n_modes(S); ++mode) {
+                ModeArgs ma = mode_args(S, g, d, mode, S->d_raw + (size_t)g * S->nphi, S->d_raw + (size_t)g * S->nphi);
+                // transverse mode index in the RT numbering: a = sum a_t (k+1)^t over the transverse axes (FEM.cpp:364-374)
+                int amode = 0, q = mode, mul = 1;
+                for (int t = 0; t < S->dim; ++t) { if (t == d) continue; amode += (q % S->n1) * mul; q /= S->n1; mul *= S->k + 1; }
+                hipLaunchKernelGGL(k_flux_to_J, dim3((unsigned)((S->nlines[d] + 63) / 64)), dim3(64), 0, st, G, ma, S->nb, amode, nfa, ni,
+                                   S->d_D + g * N, S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * S->nlines[d],
+                                   dJ + foff[d], dJ + nJface + (long)d * N * ni, S->nlines[d], S->raw_is_diag ? 1 : 0);
+            }
         HIPCHK(hipMemcpyAsync(J_host + (size_t)g * nJ, dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }

@@ -795,49 +795,74 @@ __global__ void k_prolong(const double *__restrict__ coarse, double *__restrict_
 }
 
 // J reconstruction (src/solvers.cpp:227-228 full path: J = -A^-1 B^T phi ; src/NeutFEM.cpp:620-633 diagonal
-// path: J_f = +(B^T phi)_f / A_ff).  One thread per line, Thomas in place in the face array (run once).
-__global__ void k_flux_to_J(Geom G, int d, const double *__restrict__ D, const double *__restrict__ phi,
+// path: J_f = +(B^T phi)_f / A_ff).  One thread per (line, transverse mode), Thomas in place in the face array (run
+// once, after convergence).  Face DOF (face, a) lives at face*nf + a; bubble (l, a) of cell e at e*ni + l + k*a behind the
+// faces (src/FEM.cpp:264-334, 377-397).  jface / jbub point at this direction's face / bubble block; nfa = (k+1)^(dim-1).
+__global__ void k_flux_to_J(Geom G, ModeArgs ma, int nb, int amode, int nfa, int ni, const double *__restrict__ D,
                             const double *__restrict__ L, const double *__restrict__ DR, const double *__restrict__ D0,
-                            double *__restrict__ J, long nlines, int diag)
+                            double *__restrict__ jface, double *__restrict__ jbub, long nlines, int diag)
 {
     const long line = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (line >= nlines) return;
+    const int d = ma.dir;
     int n, ix = 0, iy = 0, iz = 0; long base, sl, fbase, fsl;
     const long nxy = (long)G.nx * G.ny;
     if (d == 0) { n = G.nx; iy = (int)(line % G.ny); iz = (int)(line / G.ny); base = line * G.nx; sl = 1; fbase = line * (G.nx + 1); fsl = 1; }
     else if (d == 1) { n = G.ny; ix = (int)(line % G.nx); iz = (int)(line / G.nx); base = iz * nxy + ix; sl = G.nx;
                        fbase = (long)iz * (G.ny + 1) * G.nx + ix; fsl = G.nx; }
     else { n = G.nz; ix = (int)(line % G.nx); iy = (int)(line / G.nx); base = line; sl = nxy; fbase = line; fsl = nxy; }
+    int *ci = d == 0 ? &ix : d == 1 ? &iy : &iz;
+#define JF(f) jface[(fbase + (long)(f) * fsl) * nfa + amode]
     if (!diag) {
-        double z = -phi[base];
-        J[fbase] = z * D0[line];
-        double xc = phi[base];
+        // xL / xR of a cell (ModeArgs), forward sweep, scaling, backward sweep; faces hold z, then u, then -u
+        auto xlr = [&](int c, double &xl, double &xr) {
+            const long a = base + (long)c * sl;
+            double pl = 0.0, pr = 0.0;
+            for (int l = 0; l < nb; ++l) { const double gx = ma.Gc[l] * ma.x[l + 1][a]; pl += ma.eL[l] * gx; pr += ma.eR[l] * gx; }
+            xl = ma.x[0][a] + pl; xr = ma.x[0][a] - pr;
+        };
+        double xl, xr; xlr(0, xl, xr);
+        double z = -xl;
+        JF(0) = z * D0[line];
         for (int c = 0; c < n; ++c) {
-            const double xn = c + 1 < n ? phi[base + (long)(c + 1) * sl] : 0.0;
-            z = (xc - xn) - L[base + (long)c * sl] * z;
-            J[fbase + (long)(c + 1) * fsl] = z * DR[base + (long)c * sl];
-            xc = xn;
+            double nxl = 0.0, nxr = 0.0;
+            if (c + 1 < n) xlr(c + 1, nxl, nxr);
+            z = (xr - nxl) - L[base + (long)c * sl] * z;
+            JF(c + 1) = z * DR[base + (long)c * sl];
+            xr = nxr;
         }
-        double u = J[fbase + (long)n * fsl];
-        J[fbase + (long)n * fsl] = -u;
+        double u = JF(n);
         for (int c = n - 1; c >= 0; --c) {
-            u = J[fbase + (long)c * fsl] - L[base + (long)c * sl] * u;
-            J[fbase + (long)c * fsl] = -u;
+            const double uhi = u;
+            u = JF(c) - L[base + (long)c * sl] * u;
+            JF(c + 1) = -uhi;
+            // bubbles of cell c: v_l = G_l x_{l+1} iM_l / c_e - (eL_l u_c + eR_l u_{c+1}); inactive bubbles (l >= nb) have t_b = 0
+            if (ni > 0) {
+                *ci = c;
+                const long a = base + (long)c * sl;
+                const double ic = D[a] / geom_factor(G, d, ix, iy, iz);
+                for (int l = 0; l < G.k; ++l) {
+                    const double tb = l < nb ? ma.Gc[l] * ma.x[l + 1][a] * ma.iM[l] * ic : 0.0;
+                    const double v = tb - (ma.eL[l] * u + ma.eR[l] * uhi);
+                    jbub[a * ni + l + G.k * amode] = -v;
+                }
+            }
         }
+        JF(0) = -u;
     } else {
-        int *ci = d == 0 ? &ix : d == 1 ? &iy : &iz;
         double a2p = 0.0, a1, xp = 0.0, Dp = 0.0;
         for (int f = 0; f <= n; ++f) {
             double a2 = 0.0, xc = 0.0, Dc = 0.0;
-            if (f < n) { *ci = f; Dc = D[base + (long)f * sl]; cell_a(G, d, ix, iy, iz, Dc, a2, a1); xc = phi[base + (long)f * sl]; }
+            if (f < n) { *ci = f; Dc = D[base + (long)f * sl]; cell_a(G, d, ix, iy, iz, Dc, a2, a1); xc = ma.x[0][base + (long)f * sl]; }
             double Aff = a2p + a2;
             if (f == 0 && G.dir_lo[d]) { *ci = 0; Aff += dirichlet_term(G, d, ix, iy, iz, Dc); }
             if (f == n && G.dir_hi[d]) { *ci = n - 1; Aff += dirichlet_term(G, d, ix, iy, iz, Dp); }
             const double tt = xp - xc;                           // (B^T phi)_f / A_ff = T0 (..) / (T0 A_unit)
-            J[fbase + (long)f * fsl] = fabs(G.T0 * Aff) < 1e-14 ? 0.0 : tt / Aff;
+            JF(f) = fabs(G.T0 * Aff) < 1e-14 ? 0.0 : tt / Aff;
             a2p = a2; xp = xc; Dp = Dc;
         }
     }
+#undef JF
 }
 
 // fill with a deterministic pseudo-random pattern (profiling helper)

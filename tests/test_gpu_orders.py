@@ -74,3 +74,18 @@ def test_pybind_module_rt1_p1_flux_is_dof0():
     assert f.shape == (2, 38, 38) and m.GetNumGroups() == 4
     full = np.array(run["phi_samples"])
     assert np.isfinite(f).all() and abs(1e5 * (1 / 1.029585 - 1 / k)) < 10.0    # literature k within 10 pcm
+
+
+@pytest.mark.parametrize("rt,p,shape", [(1, 1, (9, 8, 1)), (1, 0, (9, 8, 1)), (2, 2, (6, 5, 1)), (2, 1, (7, 1, 1)), (1, 1, (6, 5, 4)), (2, 2, (4, 3, 3))])
+def test_current_reconstruction_orders(rt, p, shape):
+    """Sol_J_ = -A^-1 B^T phi for every order (src/solvers.cpp:227-228): face DOFs of all transverse modes + bubbles,
+    in the reference's DOF numbering (src/FEM.cpp:264-334)"""
+    inp = synthetic_inputs(*shape, ng=2, seed=30 + rt + p)
+    o, s = make_oracle(inp, rt, p), make_hip(inp, rt, p)
+    tol = (1e-11, 1e-11, 1e-11, 1500, 3000)
+    o.set_tol(*tol); s.set_tol(*tol)
+    o.SolveKeff(); s.solve_keff()
+    Jo, Js = o.J_dofs(), s.get_J()
+    assert Js.shape == Jo.shape
+    assert rel_l2(Js, Jo) < 1e-8
+    s.close()
