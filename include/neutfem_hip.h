@@ -99,6 +99,7 @@ typedef struct nf_keff_opts {
     int solver_type;                /* LinearSolverType 0..9 (include/solvers.hpp:176-190) */
     int solver_type_pushed;         /* 0: set_linear_solver never called -> DIRECT_LU */
     int profile;                    /* 1: bracket every Schur-apply pass with HIP events */
+    int use_cmfd;                   /* SolveKeff's 4th argument: CMFD correction from outer 2, replaces Chebyshev (:1750-1761,1786) */
 } nf_keff_opts;
 
 /* NeutFEM::SolveKeff(bool, vector<int>, bool, bool) (src/NeutFEM.cpp:1627-1815) incl. SolveCoarse
@@ -106,6 +107,14 @@ typedef struct nf_keff_opts {
  * (src/NeutFEM.cpp:2084-2105).  State kept between calls exactly like the reference:
  * current flux (nf_set_phi/nf_get_phi) and has_valid_keff_/last_keff_direct_. */
 int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_outer);
+
+/* CMFD acceleration (src/NeutFEM.cpp:662-1017, include/NeutFEM.hpp:119-143,232-235): NeutFEM::InitializeCMFD
+ * (D-tilde for every direction, D-hat = 0; idempotent until the next nf_build), SetCMFDRelaxation, and a probe that
+ * downloads D-tilde / D-hat of (group, direction) in the reference's face numbering (either pointer may be NULL).
+ * The correction itself runs inside nf_solve_keff when opts.use_cmfd is set.  Undivided meshes only. */
+int nf_initialize_cmfd(nf_handle h);
+int nf_set_cmfd_relaxation(nf_handle h, double omega);
+int nf_get_cmfd_coefficients(nf_handle h, int g, int dir, double *dtilde_host, double *dhat_host);
 
 /* NeutFEM::SolveAdjoint(normalize_to_direct, use_direct_keff) (src/NeutFEM.cpp:1877-2082, BuildFissionRHSAdjoint
  * :1568-1589): tolerances / solver type from opts; the adjoint flux is fetched with nf_get_phi_adj (host layout of phi). */

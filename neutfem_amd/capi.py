@@ -14,7 +14,7 @@ SYMBOLS = [
     "nf_last_error", "nf_device_count", "nf_create", "nf_destroy", "nf_create_slab", "nf_link_slabs", "nf_comm_unique_id",
     "nf_comm_init", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
-    "nf_solve_coarse", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
+    "nf_solve_coarse", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply",
     "nf_set_option", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
@@ -24,7 +24,7 @@ class KeffOpts(C.Structure):
     _fields_ = [("tol_keff", C.c_double), ("tol_flux", C.c_double), ("max_outer", C.c_int), ("max_inner", C.c_int),
                 ("use_coarse_init", C.c_int), ("coarse_factors", C.c_int * 3), ("n_coarse_factors", C.c_int),
                 ("use_diagonal_solver", C.c_int), ("solver_type", C.c_int), ("solver_type_pushed", C.c_int),
-                ("profile", C.c_int)]
+                ("profile", C.c_int), ("use_cmfd", C.c_int)]
 
 
 _LIB = None
@@ -64,6 +64,9 @@ def load():
     L.nf_set_phi.argtypes = [vp, dp]
     L.nf_get_phi.argtypes = [vp, dp]
     L.nf_get_J.argtypes = [vp, dp]
+    L.nf_initialize_cmfd.argtypes = [vp]
+    L.nf_set_cmfd_relaxation.argtypes = [vp, C.c_double]
+    L.nf_get_cmfd_coefficients.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.nf_reset_flux.argtypes = [vp]
     L.nf_set_warm_state.argtypes = [vp, C.c_int, C.c_double]
     L.nf_get_warm_state.argtypes = [vp, ip, dp]
@@ -177,7 +180,7 @@ class HipSolver:
         x = self._from_dev(xd.download()); bd.free(); xd.free()
         return x, its.value, res.value
 
-    def opts(self, use_coarse=False, factors=(), use_diag=False, profile=False):
+    def opts(self, use_coarse=False, factors=(), use_diag=False, profile=False, use_cmfd=False):
         o = KeffOpts()
         o.tol_keff, o.tol_flux, _, o.max_outer, o.max_inner = self.tol
         f = list(factors)[:3]
@@ -187,13 +190,25 @@ class HipSolver:
             o.coarse_factors[i] = int(v)
         o.use_diagonal_solver = int(use_diag)
         o.solver_type, o.solver_type_pushed, o.profile = self.solver_type, self.solver_pushed, int(profile)
+        o.use_cmfd = int(use_cmfd)
         return o
 
-    def solve_keff(self, use_coarse=False, factors=(), use_diag=False, profile=False):
-        o = self.opts(use_coarse, factors, use_diag, profile)
+    def solve_keff(self, use_coarse=False, factors=(), use_diag=False, profile=False, use_cmfd=False):
+        o = self.opts(use_coarse, factors, use_diag, profile, use_cmfd)
         k, n = C.c_double(), C.c_int()
         self._chk(self.L.nf_solve_keff(self.h, C.byref(o), C.byref(k), C.byref(n)))
         return k.value, n.value
+
+    def initialize_cmfd(self): self._chk(self.L.nf_initialize_cmfd(self.h))
+    def set_cmfd_relaxation(self, omega): self._chk(self.L.nf_set_cmfd_relaxation(self.h, float(omega)))
+
+    def cmfd_coefficients(self, g, direction):
+        """(D-tilde, D-hat) of group g on the faces of `direction`, reference face numbering"""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        n = [(nx + 1) * ny * nz, nx * (ny + 1) * nz, nx * ny * (nz + 1)][direction]
+        dt, dh = np.empty(n), np.empty(n)
+        self._chk(self.L.nf_get_cmfd_coefficients(self.h, g, direction, _dp(dt), _dp(dh)))
+        return dt, dh
 
     def solve_coarse(self, factors):
         o = self.opts(True, factors)

@@ -5,7 +5,7 @@
 // BC map, warm-start flags -- and hands the hot path (BuildMatrices, SolveKeff, SolveCoarse,
 // build_diagonal_cache) to the HIP library.  There is NO CPU fallback: without a HIP device those
 // methods raise RuntimeError.  Methods the reference binds but that lie outside the accelerated
-// path (adjoint, CMFD, VTK, never-defined projections) raise RuntimeError with that explanation.
+// path (never-defined projections, reflectors) raise RuntimeError with that explanation.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -91,7 +91,8 @@ public:
     void SetLinearSolver(LinearSolverType t) { solver_ = t; solver_pushed_ = true; }
     void SetTolerance(double tk, double tf, double tl, int mo, int mi) { tol_keff_ = tk; tol_flux_ = tf; tol_L2_ = tl; max_outer_ = mo; max_inner_ = mi; }
     void SetVerbosity(VerbosityLevel v) { verb_ = v; }
-    void SetCMFDRelaxation(double w) { cmfd_omega_ = w; }
+    void SetCMFDRelaxation(double w) { cmfd_omega_ = w; if (h_) nf_set_cmfd_relaxation(h_, w); }   // include/NeutFEM.hpp:232-235
+    void InitializeCMFD() { need_built("initialize_cmfd"); chk(nf_initialize_cmfd(h_)); }                 // src/NeutFEM.cpp:662-704
     void ApplyQuarterSymmetry(int, int) { SetBC(1, BCType::MIRROR, 0.0); SetBC(4, BCType::MIRROR, 0.0); }   // :356-362
     int AddReflector(py::array_t<double>, py::array_t<double>, py::array_t<double>) { return 0; }           // :2614-2620
     void SetReflector(int, int, bool) {}
@@ -129,15 +130,16 @@ public:
     }
     double SolveKeff(bool use_coarse_init, const std::vector<int> &coarse_factors, bool use_diagonal_solver, bool use_cmfd)
     {
-        if (use_cmfd) throw std::runtime_error("use_cmfd=True: CMFD acceleration is outside the accelerated hot path of neutfem_amd (reference: src/NeutFEM.cpp:662-1017)");
         need_built("SolveKeff");
         Log(VerbosityLevel::NORMAL, "\n=== CALCUL DE K-EFFECTIF (DIRECT) ===");
         if (use_diagonal_solver && !(rt_ == 0 && p_ == 0)) { Log(VerbosityLevel::NORMAL, "  Note: Solveur diagonal non disponible (ordre > 0)"); use_diagonal_solver = false; }
         if (use_diagonal_solver) Log(VerbosityLevel::NORMAL, "  Mode: Solveur diagonal RT0-P0 (faible RAM)");
-        Log(VerbosityLevel::NORMAL, "  Acceleration: Chebyshev");
+        Log(VerbosityLevel::NORMAL, use_cmfd ? "  Acceleration: CMFD active" : "  Acceleration: Chebyshev");
         chk(nf_set_phi(h_, Phi_.data()));
         chk(nf_set_warm_state(h_, has_valid_keff_ ? 1 : 0, last_keff_));
         nf_keff_opts o = make_opts(use_coarse_init, coarse_factors, use_diagonal_solver);
+        o.use_cmfd = use_cmfd ? 1 : 0;
+        chk(nf_set_cmfd_relaxation(h_, cmfd_omega_));
         double k = 1.0; int nout = 0;
         chk(nf_solve_keff(h_, &o, &k, &nout));
         chk(nf_get_phi(h_, Phi_.data()));
@@ -286,7 +288,7 @@ private:
     std::map<int, BCType> bc_types_; std::map<int, double> bc_values_; std::map<int, std::pair<double, double>> robin_;
     LinearSolverType solver_ = LinearSolverType::BICGSTAB; bool solver_pushed_ = false;   // src/NeutFEM.cpp:126 vs solvers.cpp:68
     double tol_keff_ = 1e-5, tol_flux_ = 1e-5, tol_L2_ = 1e-5; int max_outer_ = 200, max_inner_ = 1000;
-    VerbosityLevel verb_ = VerbosityLevel::NORMAL; double cmfd_omega_ = 0.7;
+    VerbosityLevel verb_ = VerbosityLevel::NORMAL; double cmfd_omega_ = 1.0;
     bool has_valid_keff_ = false;
 };
 
@@ -337,7 +339,7 @@ PYBIND11_MODULE(_neutfem_eigen, m)
         .def("SolveSubcritical", [](NeutFEM &s) { s.oos("SolveSubcritical", "declared at include/NeutFEM.hpp:279, never defined"); })
         .def("SolveCoarse", &NeutFEM::SolveCoarse, py::arg("refine"))
         .def("build_diagonal_cache", &NeutFEM::BuildDiagonalCache)
-        .def("initialize_cmfd", [](NeutFEM &s) { s.oos("initialize_cmfd", "src/NeutFEM.cpp:662-760"); })
+        .def("initialize_cmfd", &NeutFEM::InitializeCMFD)
         .def("ExportVTK", &NeutFEM::ExportVTK, py::arg("filename"), py::arg("export_flux") = true, py::arg("export_current") = true,
              py::arg("export_xs") = false, py::arg("export_adjoint") = false)
         .def("ExportFluxVTK", [](NeutFEM &s, const std::string &fn, bool adj) { s.ExportVTK(fn, true, false, false, adj); }, py::arg("filename"), py::arg("adjoint") = false)

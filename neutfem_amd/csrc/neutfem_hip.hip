@@ -137,6 +137,11 @@ struct nf_solver {
     double *d_p0 = nullptr, *d_p1 = nullptr;            // Chebyshev history
     double *d_tf = nullptr, *d_rhs = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
     bool raw_valid = false, raw_is_diag = false;
+    // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
+    bool cmfd_init = false; double cmfd_relax = 1.0;
+    double *d_Dt[3] = {nullptr, nullptr, nullptr}, *d_Dh[3] = {nullptr, nullptr, nullptr}; long nfc[3] = {0, 0, 0};
+    double *d_cm = nullptr, *d_cmJ = nullptr; CmfdScalars *d_cmsc = nullptr;
+    int cmfd_last_its = 0;
 };
 
 const char *nf_last_error(void) { return g_err.c_str(); }
@@ -337,6 +342,8 @@ int nf_destroy(nf_handle S)
     (void)hipSetDevice(S->device);
     nf_team *T = S->team;
     if (T && T->stream) (void)hipStreamSynchronize(T->stream);
+    for (int d = 0; d < 3; ++d) { dfree(S->d_Dt[d]); dfree(S->d_Dh[d]); }
+    dfree(S->d_cm); dfree(S->d_cmJ); dfree(S->d_cmsc);
     dfree(S->d_hx); dfree(S->d_hy); dfree(S->d_hz); dfree(S->d_xb); dfree(S->d_yb); dfree(S->d_zb);
     dfree(S->d_D); dfree(S->d_SigR); dfree(S->d_NSF); dfree(S->d_Chi);
     for (auto &p : S->d_SigS) dfree(p);
@@ -496,7 +503,7 @@ int nf_build(nf_handle S)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    S->built = true; S->diag_valid = false;                       // src/NeutFEM.cpp:454-456
+    S->built = true; S->diag_valid = false; S->cmfd_init = false;   // src/NeutFEM.cpp:454-456
     S->team->linked_ready = false;
     return NF_OK;
 }
@@ -1027,6 +1034,99 @@ int nf_solve_coarse(nf_handle S, const nf_keff_opts *o, double *k_coarse, double
     return NF_OK;
 }
 
+// ---- CMFD (src/NeutFEM.cpp:662-1017) -------------------------------------------------------------
+// InitializeCMFD: D~ for every direction, D^ = 0.  Idempotent until the next nf_build (is_initialized, :663).
+static int cmfd_initialize(nf_solver *S)
+{
+    if (S->cmfd_init) return NF_OK;
+    if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "CMFD is not available on a slab-decomposed mesh");
+    hipStream_t st = S->team->stream;
+    const int ng = S->ng; const long N = S->N;
+    S->nfc[0] = (long)(S->nx + 1) * S->ny * S->nz; S->nfc[1] = (long)S->nx * (S->ny + 1) * S->nz; S->nfc[2] = (long)S->nx * S->ny * (S->nz + 1);
+    Geom G = make_geom(S);
+    for (int d = 0; d < 3; ++d) {
+        NFCHK(dalloc(&S->d_Dt[d], (size_t)S->nfc[d] * ng)); NFCHK(dalloc(&S->d_Dh[d], (size_t)S->nfc[d] * ng));
+        HIPCHK(hipMemsetAsync(S->d_Dt[d], 0, (size_t)S->nfc[d] * ng * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(S->d_Dh[d], 0, (size_t)S->nfc[d] * ng * sizeof(double), st));
+        if (d >= S->dim) continue;
+        for (int g = 0; g < ng; ++g)
+            hipLaunchKernelGGL(k_cmfd_dtilde, dim3((unsigned)((S->nfc[d] + 255) / 256)), dim3(256), 0, st, G, d, S->d_D + g * N, S->d_Dt[d] + g * S->nfc[d], S->nfc[d]);
+    }
+    if (!S->d_cm) NFCHK(dalloc(&S->d_cm, (size_t)N * 6));
+    if (!S->d_cmJ) NFCHK(dalloc(&S->d_cmJ, (size_t)S->nJ));
+    if (!S->d_cmsc) NFCHK(dalloc(&S->d_cmsc, 1));
+    HIPCHK(hipGetLastError());
+    S->cmfd_init = true;
+    return NF_OK;
+}
+int nf_initialize_cmfd(nf_handle S)
+{
+    if (!S) return fail(NF_ERR_ARG, "null handle");
+    if (!S->built) return fail(NF_ERR_STATE, "nf_initialize_cmfd: call nf_build first");
+    HIPCHK(hipSetDevice(S->device));
+    NFCHK(cmfd_initialize(S));
+    HIPCHK(hipStreamSynchronize(S->team->stream));
+    return NF_OK;
+}
+int nf_set_cmfd_relaxation(nf_handle S, double omega) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->cmfd_relax = omega; return NF_OK; }
+int nf_get_cmfd_coefficients(nf_handle S, int g, int dir, double *dtilde_host, double *dhat_host)
+{
+    if (!S || g < 0 || g >= S->ng || dir < 0 || dir > 2) return fail(NF_ERR_ARG, "nf_get_cmfd_coefficients: bad arguments");
+    if (!S->cmfd_init) return fail(NF_ERR_STATE, "CMFD is not initialised");
+    HIPCHK(hipSetDevice(S->device));
+    HIPCHK(hipStreamSynchronize(S->team->stream));
+    if (dtilde_host) HIPCHK(hipMemcpy(dtilde_host, S->d_Dt[dir] + g * S->nfc[dir], S->nfc[dir] * sizeof(double), hipMemcpyDeviceToHost));
+    if (dhat_host) HIPCHK(hipMemcpy(dhat_host, S->d_Dh[dir] + g * S->nfc[dir], S->nfc[dir] * sizeof(double), hipMemcpyDeviceToHost));
+    return NF_OK;
+}
+
+// UpdateDhatCoefficients for every group, then phi_g *= ApplyCMFDCorrection(g, phi_g, total_fiss, keff) (:1750-1761).
+// phi = post-sweep group fluxes (d_raw), tf = d_tf of this outer, diag_sign = the J convention of the group solver.
+static int cmfd_step(nf_solver *S, double keff, int use_diag)
+{
+    nf_team *T = S->team; hipStream_t st = T->stream;
+    const int ng = S->ng; const long N = S->N, NP = S->nphi;
+    Geom G = make_geom(S);
+    int nfa = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nfa *= S->k + 1; ni *= S->k + 1; }
+    const long nJface = S->nJx + S->nJy + S->nJz;
+    for (int g = 0; g < ng; ++g) {
+        // Sol_J_ x-face mode 0 of group g (the only current D^ reads)
+        ModeArgs ma = mode_args(S, g, 0, 0, S->d_raw + (size_t)g * NP, S->d_raw + (size_t)g * NP);
+        hipLaunchKernelGGL(k_flux_to_J, dim3((unsigned)((S->nlines[0] + 63) / 64)), dim3(64), 0, st, G, ma, S->nb, 0, nfa, ni,
+                           S->d_D + g * N, S->d_L[0] + g * N, S->d_DR[0] + g * N, S->d_D0[0] + g * S->nlines[0],
+                           S->d_cmJ, S->d_cmJ + nJface, S->nlines[0], use_diag);
+        hipLaunchKernelGGL(k_cmfd_dhat, dim3((unsigned)((S->nfc[0] + 255) / 256)), dim3(256), 0, st, G, S->d_raw + (size_t)g * NP, S->d_cmJ, nfa,
+                           S->d_Dt[0] + g * S->nfc[0], S->d_Dh[0] + g * S->nfc[0], S->nfc[0]);
+    }
+    double *diag = S->d_cm, *x = diag + N, *r = x + N, *pp = r + N, *q = pp + N, *z = q + N;
+    const int gN = grid_for(N);
+    const long stride = T->partial_stride;
+    S->cmfd_last_its = 0;
+    for (int g = 0; g < ng; ++g) {
+        CmfdFaces F;
+        for (int d = 0; d < 3; ++d) { F.Dt[d] = S->d_Dt[d] + g * S->nfc[d]; F.Dh[d] = S->d_Dh[d] + g * S->nfc[d]; }
+        hipLaunchKernelGGL(k_cmfd_setup, dim3(gN), dim3(256), 0, st, G, F, S->d_Cd + (size_t)g * NP, S->d_Chi + g * N, S->d_tf, 1.0 / keff,
+                           diag, x, r, pp, N, T->d_partials, stride);
+        hipLaunchKernelGGL(k_cmfd_logic, dim3(1), dim3(256), 0, st, 0, T->d_partials, gN, stride, S->d_cmsc);
+        CmfdScalars hs; hs.done = 0; hs.its = 0;
+        for (int base = 0; base < 100 && !hs.done; base += 10) {
+            for (int i = 0; i < 10; ++i) {
+                hipLaunchKernelGGL(k_cmfd_matvec, dim3(gN), dim3(256), 0, st, G, F, diag, pp, q, N, S->d_cmsc, T->d_partials);
+                hipLaunchKernelGGL(k_cmfd_logic, dim3(1), dim3(256), 0, st, 1, T->d_partials, gN, stride, S->d_cmsc);
+                hipLaunchKernelGGL(k_cmfd_update, dim3(gN), dim3(256), 0, st, diag, pp, q, x, r, z, N, S->d_cmsc, T->d_partials, stride);
+                hipLaunchKernelGGL(k_cmfd_logic, dim3(1), dim3(256), 0, st, 2, T->d_partials, gN, stride, S->d_cmsc);
+                hipLaunchKernelGGL(k_cmfd_pupdate, dim3(gN), dim3(256), 0, st, z, pp, N, S->d_cmsc);
+            }
+            HIPCHK(hipMemcpyAsync(&hs, S->d_cmsc, sizeof(hs), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        S->cmfd_last_its += hs.its;
+        hipLaunchKernelGGL(k_cmfd_correct, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, S->d_raw + (size_t)g * NP, N, S->nloc, S->cmfd_relax);
+    }
+    HIPCHK(hipGetLastError());
+    return NF_OK;
+}
+
 // ---- SolveKeff (src/NeutFEM.cpp:1627-1815) -----------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, int *n_outer)
 {
@@ -1037,6 +1137,11 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     NFCHK(team_prepare(T));
     int use_diag = (o->use_diagonal_solver && S0->k == 0 && S0->m == 0) ? 1 : 0;   // flag dropped for order > 0 (:1640-1644)
     if (use_diag) { if (!single) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh"); NFCHK(nf_build_diagonal_cache(S0)); }
+    const bool use_cmfd = o->use_cmfd != 0;
+    if (use_cmfd) {                                               // :1655-1658
+        if (!single) return fail(NF_ERR_UNSUPPORTED, "CMFD is not available on a slab-decomposed mesh");
+        NFCHK(cmfd_initialize(S0));
+    }
     double keff = T->has_valid_keff ? T->last_keff : 1.0;        // :1662
     T->coarse_outer = 0;
     if (o->use_coarse_init && o->n_coarse_factors > 0) {          // :1665-1670
@@ -1084,6 +1189,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             if (!use_diag) NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr));
             T->hist_cg.push_back(its); T->last_cg_total += its;
         }
+        if (use_cmfd && it >= 2) NFCHK(cmfd_step(S0, keff, use_diag));   // :1750-1761
         // prod_new, norms (:1766-1779)
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
@@ -1101,7 +1207,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             return fail(NF_ERR_NUMERIC, "power iteration diverged (outer %d: k=%g dphi=%g)", it, keff_new, dphi);
         // normalise + Chebyshev (:1780-1788, src/solvers.cpp:720-756)
         int mode = 0; double a = 0.0, b = 0.0;
-        if (it >= 2) {
+        if (it >= 2 && !use_cmfd) {                               // :1786-1788
             if (cheb_it == nmax) cheb_it = 0;
             if (cheb_it == 0) { mode = 1; }
             else if (cheb_it == 1) { mode = 2; a = ca[1]; }
@@ -1114,7 +1220,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
                                norm > 1e-14 ? 1 : 0, mode, a, b);
             if (mode == 3) std::swap(S->d_p0, S->d_p1);
         }
-        if (it >= 2) ++cheb_it;
+        if (it >= 2 && !use_cmfd) ++cheb_it;
         T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
         T->last_outer = it + 1;
         if (dk < o->tol_keff && dphi < o->tol_flux) break;        // :1799-1802

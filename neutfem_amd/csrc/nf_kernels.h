@@ -865,6 +865,177 @@ __global__ void k_flux_to_J(Geom G, ModeArgs ma, int nb, int amode, int nfa, int
 #undef JF
 }
 
+// ---------------------------------------------------------------------------------------------
+// CMFD acceleration (src/NeutFEM.cpp:662-1017).  A 7-point finite-volume operator per group on the cell grid,
+//   M = diag(C_00 + sum_faces Deff A_face) - offdiag(Deff A_face),  Deff = D~ + D^,
+// solved with Eigen's diagonally preconditioned CG (tolerance 1e-8 on |r|/|b|, at most 100 iterations, x0 = 0).  Face
+// coefficients are stored per direction with the reference's face numbering (x: iz*ny*(nx+1) + iy*(nx+1) + ix, ...).
+struct CmfdFaces { const double *Dt[3]; const double *Dh[3]; };
+struct CmfdScalars { double absNew, alpha, beta, thr; int done, its; };
+
+__device__ __forceinline__ double cmfd_face_area(const Geom &G, int d, int ix, int iy, int iz)
+{
+    return d == 0 ? G.hy[iy] * G.hz[iz] : d == 1 ? G.hx[ix] * G.hz[iz] : G.hx[ix] * G.hy[iy];
+}
+__device__ __forceinline__ long cmfd_face(const Geom &G, int d, int ix, int iy, int iz)
+{
+    if (d == 0) return ((long)iz * G.ny + iy) * (G.nx + 1) + ix;
+    if (d == 1) return ((long)iz * (G.ny + 1) + iy) * G.nx + ix;
+    return ((long)iz * G.ny + iy) * G.nx + ix;
+}
+// ComputeDtildeCoefficients (:723-821): harmonic mean inside, 2D/h on the boundary.  One thread per face of direction d.
+__global__ void k_cmfd_dtilde(Geom G, int d, const double *__restrict__ D, double *__restrict__ Dt, long nfaces)
+{
+    const long f = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (f >= nfaces) return;
+    const int n0 = d == 0 ? G.nx + 1 : G.nx, n1 = d == 1 ? G.ny + 1 : G.ny;
+    int c[3] = { (int)(f % n0), (int)((f / n0) % n1), (int)(f / ((long)n0 * n1)) };
+    const int nd = d == 0 ? G.nx : d == 1 ? G.ny : G.nz;
+    const double *h = d == 0 ? G.hx : d == 1 ? G.hy : G.hz;
+    const int cd = c[d];
+    const long st = d == 0 ? 1 : d == 1 ? G.nx : (long)G.nx * G.ny;
+    c[d] = cd == 0 ? 0 : cd - 1;                                  // lower (or only) neighbour
+    const long eL = ((long)c[2] * G.ny + c[1]) * G.nx + c[0];
+    double v;
+    if (cd == 0 || cd == nd) v = 2.0 * D[eL] / h[c[d]];
+    else { const double DL = D[eL], DR = D[eL + st], dL = h[cd - 1], dR = h[cd]; v = 2.0 * DL * DR / (DL * dR + DR * dL); }
+    Dt[f] = v;
+}
+// UpdateDhatCoefficients (:823-869): x faces only; Jx holds the mode-0 face current at stride nfa.
+__global__ void k_cmfd_dhat(Geom G, const double *__restrict__ phi, const double *__restrict__ Jx, int nfa,
+                            const double *__restrict__ Dt, double *__restrict__ Dh, long nfaces)
+{
+    const long f = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (f >= nfaces) return;
+    const int ix = (int)(f % (G.nx + 1)); const long line = f / (G.nx + 1);
+    const long eR = line * G.nx + ix, eL = eR - 1;
+    const double pd = ix == 0 ? -phi[eR] : ix == G.nx ? phi[eL] : phi[eL] - phi[eR];
+    Dh[f] = fabs(pd) > 1e-14 ? Jx[f * nfa] / pd - Dt[f] : 0.0;
+}
+__device__ __forceinline__ void cmfd_cell(const Geom &G, long e, int &ix, int &iy, int &iz)
+{
+    ix = (int)(e % G.nx); iy = (int)((e / G.nx) % G.ny); iz = (int)(e / ((long)G.nx * G.ny));
+}
+// diag, rhs = chi tf / k, x = 0, r = rhs, p = z = r / diag ; partials: [0] |rhs|^2, [1] r.z
+__global__ __launch_bounds__(256) void k_cmfd_setup(Geom G, CmfdFaces F, const double *__restrict__ C00, const double *__restrict__ chi,
+                                                    const double *__restrict__ tf, double inv_k, double *__restrict__ diag,
+                                                    double *__restrict__ x, double *__restrict__ r, double *__restrict__ pp,
+                                                    long N, double *__restrict__ partials, long stride)
+{
+    __shared__ double sred[4];
+    double s0 = 0.0, s1 = 0.0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < N; e += gridDim.x * 256L) {
+        int c[3]; cmfd_cell(G, e, c[0], c[1], c[2]);
+        double dg = C00[e];
+        for (int d = 0; d < G.dim; ++d) {
+            const double A = cmfd_face_area(G, d, c[0], c[1], c[2]);
+            const long fl = cmfd_face(G, d, c[0], c[1], c[2]);
+            c[d] += 1; const long fu = cmfd_face(G, d, c[0], c[1], c[2]); c[d] -= 1;
+            dg += ((F.Dt[d][fl] + F.Dh[d][fl]) + (F.Dt[d][fu] + F.Dh[d][fu])) * A;
+        }
+        const double b = chi[e] * tf[e] * inv_k;
+        const double z = (dg != 0.0 ? 1.0 / dg : 1.0) * b;             // DiagonalPreconditioner stores 1/diag
+        diag[e] = dg; x[e] = 0.0; r[e] = b; pp[e] = z;
+        s0 += b * b; s1 += b * z;
+    }
+    s0 = block_sum(s0, sred); s1 = block_sum(s1, sred);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[stride + blockIdx.x] = s1; }
+}
+// q = M p ; partial p.q
+__global__ __launch_bounds__(256) void k_cmfd_matvec(Geom G, CmfdFaces F, const double *__restrict__ diag, const double *__restrict__ pp,
+                                                     double *__restrict__ q, long N, const CmfdScalars *__restrict__ sc,
+                                                     double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    if (sc->done) return;
+    const long nxy = (long)G.nx * G.ny;
+    double s0 = 0.0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < N; e += gridDim.x * 256L) {
+        int c[3]; cmfd_cell(G, e, c[0], c[1], c[2]);
+        const double pe = pp[e];
+        double s = diag[e] * pe;
+        for (int d = 0; d < G.dim; ++d) {
+            const int cd = c[d], nd = d == 0 ? G.nx : d == 1 ? G.ny : G.nz;
+            const long st = d == 0 ? 1 : d == 1 ? G.nx : nxy;
+            const double A = cmfd_face_area(G, d, c[0], c[1], c[2]);
+            const long fl = cmfd_face(G, d, c[0], c[1], c[2]);
+            c[d] += 1; const long fu = cmfd_face(G, d, c[0], c[1], c[2]); c[d] -= 1;
+            if (cd > 0) s -= (F.Dt[d][fl] + F.Dh[d][fl]) * A * pp[e - st];
+            if (cd < nd - 1) s -= (F.Dt[d][fu] + F.Dh[d][fu]) * A * pp[e + st];
+        }
+        q[e] = s; s0 += pe * s;
+    }
+    s0 = block_sum(s0, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s0;
+}
+// x += alpha p ; r -= alpha q ; z = r / diag ; partials: [0] |r|^2, [1] r.z
+__global__ __launch_bounds__(256) void k_cmfd_update(const double *__restrict__ diag, const double *__restrict__ pp, const double *__restrict__ q,
+                                                     double *__restrict__ x, double *__restrict__ r, double *__restrict__ z, long N,
+                                                     const CmfdScalars *__restrict__ sc, double *__restrict__ partials, long stride)
+{
+    __shared__ double sred[4];
+    if (sc->done) return;
+    const double alpha = sc->alpha;
+    double s0 = 0.0, s1 = 0.0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < N; e += gridDim.x * 256L) {
+        x[e] += alpha * pp[e];
+        const double re = r[e] - alpha * q[e];
+        const double dg = diag[e], ze = (dg != 0.0 ? 1.0 / dg : 1.0) * re;
+        r[e] = re; z[e] = ze;
+        s0 += re * re; s1 += re * ze;
+    }
+    s0 = block_sum(s0, sred); s1 = block_sum(s1, sred);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[stride + blockIdx.x] = s1; }
+}
+__global__ void k_cmfd_pupdate(const double *__restrict__ z, double *__restrict__ pp, long N, const CmfdScalars *__restrict__ sc)
+{
+    if (sc->done) return;
+    const double beta = sc->beta;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < N; e += gridDim.x * 256L) pp[e] = z[e] + beta * pp[e];
+}
+// second reduction stage + Eigen's conjugate_gradient() scalar logic.  One block of 256 threads.
+// op 0: after setup (rhs2, r.z) ; op 1: after matvec (p.q) ; op 2: after update (|r|^2, r.z)
+__global__ __launch_bounds__(256) void k_cmfd_logic(int op, const double *__restrict__ partials, int cnt, long stride,
+                                                    CmfdScalars *__restrict__ sc)
+{
+    __shared__ double sred[4];
+    if (op != 0 && sc->done) return;
+    double tot[2] = { 0.0, 0.0 };
+    const int nq = op == 1 ? 1 : 2;
+    for (int q = 0; q < nq; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < cnt; i += 256) s += partials[q * stride + i];
+        tot[q] = block_sum(s, sred);
+    }
+    if (threadIdx.x != 0) return;
+    if (op == 0) {
+        sc->its = 0; sc->alpha = sc->beta = 0.0;
+        const double rhs2 = tot[0];
+        sc->thr = fmax(1e-8 * 1e-8 * rhs2, 2.2250738585072014e-308);
+        sc->absNew = tot[1];
+        sc->done = (rhs2 == 0.0 || rhs2 < sc->thr) ? 1 : 0;
+    } else if (op == 1) {
+        sc->alpha = sc->absNew / tot[0];
+    } else {
+        sc->its += 1;
+        if (tot[0] < sc->thr) { sc->done = 1; return; }
+        sc->beta = tot[1] / sc->absNew;
+        sc->absNew = tot[1];
+        if (sc->its >= 100) sc->done = 1;
+    }
+}
+// ratio clamp + relaxation (:994-1014); the correction multiplies every moment of the cell
+__global__ void k_cmfd_correct(const double *__restrict__ x, double *__restrict__ phi, long N, int nloc, double omega)
+{
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const double pc = phi[e];
+    double ratio = 1.0;
+    if (fabs(pc) > 1e-14) { ratio = x[e] / pc; ratio = fmax(0.5, fmin(2.0, ratio)); }
+    const double corr = omega * ratio + (1.0 - omega) * 1.0;
+    for (int l = 0; l < nloc; ++l) phi[l * N + e] *= corr;
+}
+
 // fill with a deterministic pseudo-random pattern (profiling helper)
 __global__ void k_fill_pattern(double *__restrict__ v, long n)
 {

@@ -41,6 +41,9 @@ struct nfo {
     /* XS + solution (host) */
     double *D, *SigR, *NSF, *KSF, *Chi, *SRC, *SigS, *phi, *J, *phi_adj;
     double last_keff_adj; int has_valid_adjoint;
+    /* CMFD (include/NeutFEM.hpp:119-143) */
+    int cmfd_init; double cmfd_relax; double *Dt[3], *Dh[3];   /* per direction: ng * n_faces_dir */
+    long nfc[3];
     int bc_set[8], bc_type[8]; double bc_val[8];
     double tol_keff, tol_flux, tol_L2; int max_outer, max_inner;
     int solver_type, solver_type_pushed;    /* NeutFEM.cpp:126 vs solvers.cpp:68 */
@@ -370,6 +373,8 @@ nfo_t *nfo_create(int rt_order, int p_order, int ng, int nxb, const double *xb, 
     h->phi_adj = (double *)malloc(sizeof(double) * ng * h->nPhi);
     for (long i = 0; i < ng * h->nPhi; ++i) h->phi_adj[i] = 1.0;
     h->last_keff_adj = 1.0; h->has_valid_adjoint = 0;
+    h->cmfd_init = 0; h->cmfd_relax = 1.0;
+    h->nfc[0] = (long)(h->nx + 1) * h->ny * h->nz; h->nfc[1] = (long)h->nx * (h->ny + 1) * h->nz; h->nfc[2] = (long)h->nx * h->ny * (h->nz + 1);
     h->tol_keff = h->tol_flux = h->tol_L2 = 1e-5; h->max_outer = 200; h->max_inner = 1000;
     h->solver_type = 6; h->solver_type_pushed = 0;             /* BICGSTAB shown, DIRECT_LU used (quirk 11) */
     h->schur_tol = 1e-10; h->schur_maxit = 1000;               /* solvers.cpp:67-76 */
@@ -405,6 +410,7 @@ void nfo_destroy(nfo_t *h)
     free(h->D); free(h->SRC); free(h->SigR); free(h->NSF); free(h->KSF); free(h->Chi); free(h->SigS); free(h->phi); free(h->J); free(h->phi_adj);
     for (int d = 0; d < 3; ++d) free(h->Ahat[d]);
     free(h->Bhat); free(h->Chat); free(h->hist_cg);
+    for (int d = 0; d < 3; ++d) { free(h->Dt[d]); free(h->Dh[d]); }
     free(h);
 }
 
@@ -534,7 +540,7 @@ int nfo_build(nfo_t *h)
     h->Ms = (double **)calloc((size_t)ng * ng, sizeof(double *)); h->Sinv = (double **)calloc(ng, sizeof(double *));
     h->eJ = (int *)malloc(sizeof(int) * ne * nJl);
     h->wt = (double *)malloc(sizeof(double) * nJ); h->wu = (double *)malloc(sizeof(double) * nJ);
-    h->built = 1; h->diag_valid = 0;
+    h->built = 1; h->diag_valid = 0; h->cmfd_init = 0;             /* NeutFEM.cpp:454-456 */
     for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
         long e = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix;
         for (int j = 0; j < nJl; ++j) h->eJ[e * nJl + j] = (int)chain_pos(h, ix, iy, iz, j);
@@ -771,12 +777,163 @@ static void cheb_apply(cheb_t *c, double *phi)
 }
 static void cheb_free(cheb_t *c) { free(c->p0); free(c->p1); }
 
+/* ---- CMFD acceleration, src/NeutFEM.cpp:662-1017 (x-direction D-hat only, as the reference) ---------------------- */
+void nfo_set_cmfd_relaxation(nfo_t *h, double omega) { h->cmfd_relax = omega; }
+static long cmfd_face(const nfo_t *h, int d, int ix, int iy, int iz)
+{
+    if (d == 0) return (long)iz * h->ny * (h->nx + 1) + (long)iy * (h->nx + 1) + ix;
+    if (d == 1) return (long)iz * (h->ny + 1) * h->nx + (long)iy * h->nx + ix;
+    return (long)iz * h->ny * h->nx + (long)iy * h->nx + ix;
+}
+/* InitializeCMFD + ComputeDtildeCoefficients (:662-821) */
+static void cmfd_initialize(nfo_t *h)
+{
+    if (h->cmfd_init) return;
+    const int ng = h->ng; const long ne = h->ne;
+    for (int d = 0; d < 3; ++d) {
+        free(h->Dt[d]); free(h->Dh[d]);
+        h->Dt[d] = (double *)calloc((size_t)ng * h->nfc[d], sizeof(double));
+        h->Dh[d] = (double *)calloc((size_t)ng * h->nfc[d], sizeof(double));
+    }
+    for (int g = 0; g < ng; ++g)
+        for (int d = 0; d < h->dim; ++d) {
+            const int nd = d == 0 ? h->nx : d == 1 ? h->ny : h->nz;
+            const double *brk = d == 0 ? h->xb : d == 1 ? h->yb : h->zb;
+            const int n0 = d == 0 ? nd + 1 : h->nx, n1 = d == 1 ? nd + 1 : h->ny, n2 = d == 2 ? nd + 1 : h->nz;
+            for (int iz = 0; iz < n2; ++iz) for (int iy = 0; iy < n1; ++iy) for (int ix = 0; ix < n0; ++ix) {
+                const int c = d == 0 ? ix : d == 1 ? iy : iz;
+                int lo[3] = { ix, iy, iz }, hi[3] = { ix, iy, iz };
+                double v;
+                if (c == 0 || c == nd) {
+                    lo[d] = c == 0 ? 0 : nd - 1;
+                    long e = (long)lo[2] * h->nx * h->ny + (long)lo[1] * h->nx + lo[0];
+                    double D = h->D[g * ne + e];
+                    double dx = brk[c == 0 ? 1 : nd] - brk[c == 0 ? 0 : nd - 1];
+                    v = 2.0 * D / dx;
+                } else {
+                    lo[d] = c - 1; hi[d] = c;
+                    long eL = (long)lo[2] * h->nx * h->ny + (long)lo[1] * h->nx + lo[0], eR = (long)hi[2] * h->nx * h->ny + (long)hi[1] * h->nx + hi[0];
+                    double DL = h->D[g * ne + eL], DR = h->D[g * ne + eR];
+                    double dL = brk[c] - brk[c - 1], dR = brk[c + 1] - brk[c];
+                    v = 2.0 * DL * DR / (DL * dR + DR * dL);
+                }
+                h->Dt[d][g * h->nfc[d] + cmfd_face(h, d, ix, iy, iz)] = v;
+            }
+        }
+    h->cmfd_init = 1;
+}
+/* UpdateDhatCoefficients (:823-869): x faces only */
+static void cmfd_update_dhat(nfo_t *h)
+{
+    const int dpe = h->nloc;
+    for (int g = 0; g < h->ng; ++g) {
+        const double *phi = h->phi + g * h->nPhi, *J = h->J + g * h->nJ;
+        for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix <= h->nx; ++ix) {
+            long f = cmfd_face(h, 0, ix, iy, iz);
+            double Jn = J[JxFace(h, ix, iy, iz, 0)], pd;
+            long eL = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix - 1, eR = eL + 1;
+            if (ix == 0) pd = -phi[eR * dpe]; else if (ix == h->nx) pd = phi[eL * dpe]; else pd = phi[eL * dpe] - phi[eR * dpe];
+            h->Dh[0][g * h->nfc[0] + f] = fabs(pd) > 1e-14 ? Jn / pd - h->Dt[0][g * h->nfc[0] + f] : 0.0;
+        }
+    }
+}
+/* y = M_cmfd p (7-point operator of ApplyCMFDCorrection, :893-972), matrix-free */
+static void cmfd_matvec(const nfo_t *h, int g, const double *diag, const double *p, double *y)
+{
+    const long nxy = (long)h->nx * h->ny;
+    for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
+        long e = (long)iz * nxy + (long)iy * h->nx + ix;
+        double s = diag[e] * p[e];
+        for (int d = 0; d < h->dim; ++d) {
+            const int c = d == 0 ? ix : d == 1 ? iy : iz, nd = d == 0 ? h->nx : d == 1 ? h->ny : h->nz;
+            const long st = d == 0 ? 1 : d == 1 ? h->nx : nxy;
+            const double A = face_area(h, ix, iy, iz, d);
+            int u[3] = { ix, iy, iz }; u[d] += 1;
+            const long fl = g * h->nfc[d] + cmfd_face(h, d, ix, iy, iz), fu = g * h->nfc[d] + cmfd_face(h, d, u[0], u[1], u[2]);
+            if (c > 0) s -= (h->Dt[d][fl] + h->Dh[d][fl]) * A * p[e - st];
+            if (c < nd - 1) s -= (h->Dt[d][fu] + h->Dh[d][fu]) * A * p[e + st];
+        }
+        y[e] = s;
+    }
+}
+/* ApplyCMFDCorrection (:871-1017).  The linear solve is Eigen::ConjugateGradient<SpMat, Lower|Upper> with its default
+ * DiagonalPreconditioner, tolerance 1e-8, 100 iterations, x0 = 0 -- restated from Eigen 3.4's published algorithm
+ * (Eigen/src/IterativeLinearSolvers/ConjugateGradient.h: conjugate_gradient()). */
+static void cmfd_correction(nfo_t *h, int g, const double *tf, double keff, double *corr)
+{
+    const long ne = h->ne; const int dpe = h->nloc;
+    double *diag = (double *)malloc(sizeof(double) * ne * 7), *rhs = diag + ne, *x = rhs + ne, *r = x + ne, *pp = r + ne, *z = pp + ne, *tmp = z + ne;
+    for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
+        long e = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix;
+        double dg = h->Cd[g][e * dpe];
+        for (int d = 0; d < h->dim; ++d) {
+            int u[3] = { ix, iy, iz }; u[d] += 1;
+            const long fl = g * h->nfc[d] + cmfd_face(h, d, ix, iy, iz), fu = g * h->nfc[d] + cmfd_face(h, d, u[0], u[1], u[2]);
+            dg += ((h->Dt[d][fl] + h->Dh[d][fl]) + (h->Dt[d][fu] + h->Dh[d][fu])) * face_area(h, ix, iy, iz, d);
+        }
+        diag[e] = dg;
+        rhs[e] = h->Chi[g * ne + e] * tf[e * dpe] / keff;
+    }
+    double rhs2 = 0.0; for (long e = 0; e < ne; ++e) { x[e] = 0.0; r[e] = rhs[e]; rhs2 += rhs[e] * rhs[e]; }
+    if (rhs2 > 0.0) {
+        const double thr = fmax(1e-8 * 1e-8 * rhs2, 2.2250738585072014e-308);
+        double rn2 = rhs2;
+        if (!(rn2 < thr)) {
+            double absNew = 0.0;
+            for (long e = 0; e < ne; ++e) { pp[e] = (diag[e] != 0.0 ? 1.0 / diag[e] : 1.0) * r[e]; absNew += r[e] * pp[e]; }   /* DiagonalPreconditioner: m_invdiag * b */
+            for (int i = 0; i < 100; ++i) {
+                cmfd_matvec(h, g, diag, pp, tmp);
+                double pt = 0.0; for (long e = 0; e < ne; ++e) pt += pp[e] * tmp[e];
+                const double alpha = absNew / pt;
+                rn2 = 0.0;
+                for (long e = 0; e < ne; ++e) { x[e] += alpha * pp[e]; r[e] -= alpha * tmp[e]; rn2 += r[e] * r[e]; }
+                if (rn2 < thr) break;
+                double absOld = absNew; absNew = 0.0;
+                for (long e = 0; e < ne; ++e) { z[e] = (diag[e] != 0.0 ? 1.0 / diag[e] : 1.0) * r[e]; absNew += r[e] * z[e]; }
+                const double beta = absNew / absOld;
+                for (long e = 0; e < ne; ++e) pp[e] = z[e] + beta * pp[e];
+            }
+        }
+    }
+    const double om = h->cmfd_relax;
+    for (long e = 0; e < ne; ++e) {
+        double ratio = 1.0, pc = h->phi[g * h->nPhi + e * dpe];
+        if (fabs(pc) > 1e-14) { ratio = x[e] / pc; ratio = fmax(0.5, fmin(2.0, ratio)); }
+        for (int d = 0; d < dpe; ++d) corr[e * dpe + d] = om * ratio + (1.0 - om) * 1.0;
+    }
+    free(diag);
+}
+
+/* probes: D-tilde / D-hat of (group, direction); one UpdateDhat + ApplyCMFDCorrection on the current phi / J */
+long nfo_cmfd_coefficients(nfo_t *h, int g, int dir, double *dt, double *dh)
+{
+    cmfd_initialize(h);
+    for (long f = 0; f < h->nfc[dir]; ++f) { if (dt) dt[f] = h->Dt[dir][g * h->nfc[dir] + f]; if (dh) dh[f] = h->Dh[dir][g * h->nfc[dir] + f]; }
+    return h->nfc[dir];
+}
+void nfo_cmfd_probe(nfo_t *h, int g, const double *tf, double keff, double *corr)
+{
+    cmfd_initialize(h);
+    cmfd_update_dhat(h);
+    cmfd_correction(h, g, tf, keff, corr);
+}
+
 /* SolveKeff, src/NeutFEM.cpp:1627-1815 */
+static double solve_keff_impl(nfo_t *h, int use_coarse_init, const int *factors, int nfactors, int use_diag, int use_cmfd);
 double nfo_solve_keff(nfo_t *h, int use_coarse_init, const int *factors, int nfactors, int use_diag)
+{
+    return solve_keff_impl(h, use_coarse_init, factors, nfactors, use_diag, 0);
+}
+double nfo_solve_keff_cmfd(nfo_t *h, int use_coarse_init, const int *factors, int nfactors, int use_diag, int use_cmfd)
+{
+    return solve_keff_impl(h, use_coarse_init, factors, nfactors, use_diag, use_cmfd);
+}
+static double solve_keff_impl(nfo_t *h, int use_coarse_init, const int *factors, int nfactors, int use_diag, int use_cmfd)
 {
     const int ng = h->ng; const long nP = h->nPhi, ne = h->ne, nJ = h->nJ; const int dpe = h->nloc;
     if (use_diag && !(h->k == 0 && h->m == 0)) use_diag = 0;
     if (use_diag) build_diag_cache(h);
+    if (use_cmfd) cmfd_initialize(h);                            /* :1655-1658 */
     double keff = h->has_valid_keff ? h->last_keff : 1.0;
     h->coarse_outer = 0;
     if (use_coarse_init && nfactors > 0) {
@@ -818,6 +975,13 @@ double nfo_solve_keff(nfo_t *h, int use_coarse_init, const int *factors, int nfa
             if (it < MAXHIST) h->hist_cg[(long)it * ng + g] = its;
             h->last_cg_total += its;
         }
+        if (use_cmfd && it >= 2) {                                /* :1750-1761 */
+            cmfd_update_dhat(h);
+            for (int g = 0; g < ng; ++g) {
+                cmfd_correction(h, g, tf, keff, sol);
+                for (long i = 0; i < nP; ++i) h->phi[g * nP + i] *= sol[i];
+            }
+        }
         double prod_new = 0.0;
         for (int g = 0; g < ng; ++g) for (long i = 0; i < nP; ++i) prod_new += h->Mf[g][i] * h->phi[g * nP + i];
         const double keff_new = keff * (prod_new / prod_old);
@@ -827,7 +991,7 @@ double nfo_solve_keff(nfo_t *h, int use_coarse_init, const int *factors, int nfa
         for (long i = 0; i < ng * nP; ++i) { nsq += h->phi[i] * h->phi[i]; double d = h->phi[i] - old[i]; dsq += d * d; }
         const double dphi = sqrt(dsq / nsq), norm = sqrt(nsq);
         if (norm > 1e-14) for (long i = 0; i < ng * nP; ++i) h->phi[i] /= norm;
-        if (it >= 2) cheb_apply(&acc, h->phi);
+        if (!use_cmfd && it >= 2) cheb_apply(&acc, h->phi);
         if (it < MAXHIST) { h->hist_k[it] = keff; h->hist_dk[it] = dk; h->hist_dphi[it] = dphi; }
         h->last_outer = it + 1;
         if (dk < h->tol_keff && dphi < h->tol_flux) break;

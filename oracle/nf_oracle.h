@@ -60,6 +60,14 @@ int nfo_solve_group(nfo_t *h, int g, const double *rhs, double *phi, double *J);
 /* src/NeutFEM.cpp:1627-1815 */
 double nfo_solve_keff(nfo_t *h, int use_coarse_init, const int *factors, int nfactors,
                       int use_diagonal_solver);
+/* same with use_cmfd (CMFD acceleration, src/NeutFEM.cpp:662-1017,1750-1761); nfo_set_cmfd_relaxation = set_cmfd_relaxation */
+double nfo_solve_keff_cmfd(nfo_t *h, int use_coarse_init, const int *factors, int nfactors,
+                           int use_diagonal_solver, int use_cmfd);
+void nfo_set_cmfd_relaxation(nfo_t *h, double omega);
+/* probes: D-tilde/D-hat (src/NeutFEM.cpp:723-869; returns the face count) and one UpdateDhat + ApplyCMFDCorrection
+ * (:823-1017) on the handle's current phi / J with the given total fission source (n_phi) and k */
+long nfo_cmfd_coefficients(nfo_t *h, int g, int dir, double *dtilde, double *dhat);
+void nfo_cmfd_probe(nfo_t *h, int g, const double *total_fiss, double keff, double *corr);
 /* src/NeutFEM.cpp:2380-2611 ; phi_out has ng*n_phi entries */
 double nfo_solve_coarse(nfo_t *h, const int *factors, int nfactors, double *phi_out);
 /* src/NeutFEM.cpp:483-597 ; returns S_inv for group g (ne entries) or NULL */

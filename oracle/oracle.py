@@ -50,6 +50,12 @@ def lib():
         L.nfo_solve_group.argtypes = [vp, C.c_int, dp, dp, dp]
         L.nfo_solve_keff.restype = C.c_double
         L.nfo_solve_keff.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int]
+        L.nfo_solve_keff_cmfd.restype = C.c_double
+        L.nfo_solve_keff_cmfd.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int, C.c_int]
+        L.nfo_set_cmfd_relaxation.argtypes = [vp, C.c_double]
+        L.nfo_cmfd_coefficients.restype = C.c_long
+        L.nfo_cmfd_coefficients.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+        L.nfo_cmfd_probe.argtypes = [vp, C.c_int, dp, C.c_double, dp]
         L.nfo_solve_coarse.restype = C.c_double
         L.nfo_solve_coarse.argtypes = [vp, ip, C.c_int, dp]
         L.nfo_diag_cache.restype = dp
@@ -132,11 +138,23 @@ class OracleNeutFEM:
             raise RuntimeError(f"oracle build failed ({rc})")
 
     def SolveKeff(self, use_coarse_init=False, coarse_factors=(), use_diagonal_solver=False, use_cmfd=False):
-        if use_cmfd:
-            raise NotImplementedError("CMFD is out of scope (SURVEY 8f-3)")
         f = np.asarray(list(coarse_factors), dtype=np.int32)
-        return self._L.nfo_solve_keff(self._h, int(use_coarse_init), f.ctypes.data_as(C.POINTER(C.c_int)), len(f),
-                                      int(use_diagonal_solver))
+        return self._L.nfo_solve_keff_cmfd(self._h, int(use_coarse_init), f.ctypes.data_as(C.POINTER(C.c_int)), len(f),
+                                           int(use_diagonal_solver), int(use_cmfd))
+
+    def set_cmfd_relaxation(self, omega): self._L.nfo_set_cmfd_relaxation(self._h, float(omega))
+
+    def cmfd_coefficients(self, g, direction):
+        nx, ny, nz = self.nx, self.ny, self.nz
+        n = [(nx + 1) * ny * nz, nx * (ny + 1) * nz, nx * ny * (nz + 1)][direction]
+        dt, dh = np.zeros(n), np.zeros(n)
+        self._L.nfo_cmfd_coefficients(self._h, g, direction, _dp(dt), _dp(dh))
+        return dt, dh
+
+    def cmfd_probe(self, g, total_fiss, keff):
+        tf = np.ascontiguousarray(total_fiss, dtype=np.float64); corr = np.zeros(self.n_phi)
+        self._L.nfo_cmfd_probe(self._h, g, _dp(tf), float(keff), _dp(corr))
+        return corr
 
     def SolveCoarse(self, refine):
         f = np.asarray(list(refine), dtype=np.int32)

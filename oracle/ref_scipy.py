@@ -213,8 +213,71 @@ class RefScipy:
     def set_tol(self, tk, tf, tl, mo, mi):
         self.tol = (tk, tf, tl, mo, mi); self.cg_tol = tf; self.cg_max = mi
 
-    def solve_keff(self, use_coarse=False, factors=(), use_diag=False):   # NeutFEM.cpp:1627-1815
+    # ---- CMFD (NeutFEM.cpp:662-1017) with an explicit scipy matrix and Eigen's PCG written out in numpy -------------
+    def cmfd_init(self):
+        nx, ny, nz, ng = self.nx, self.ny, self.nz, self.ng
+        shp = [(nz, ny, nx + 1), (nz, ny + 1, nx), (nz + 1, ny, nx)]
+        self.Dt = [np.zeros((ng,) + s_) for s_ in shp]; self.Dh = [np.zeros((ng,) + s_) for s_ in shp]
+        hs = [self.hx, self.hy, self.hz]
+        for g in range(ng):
+            D = self.D[g].reshape(nz, ny, nx)
+            for d in range(self.dim):
+                ax = 2 - d                                       # array axis of direction d
+                Dm = np.moveaxis(D, ax, 0); h = hs[d].reshape((-1,) + (1,) * 2)
+                out = np.moveaxis(self.Dt[d][g], ax, 0)
+                out[0] = 2 * Dm[0] / h[0]; out[-1] = 2 * Dm[-1] / h[-1]
+                out[1:-1] = 2 * Dm[:-1] * Dm[1:] / (Dm[:-1] * h[1:] + Dm[1:] * h[:-1])
+
+    def cmfd_dhat(self, J):
+        nx, ny, nz, nf = self.nx, self.ny, self.nz, self.nf
+        for g in range(self.ng):
+            phi = self.phi[g * self.nPhi:(g + 1) * self.nPhi].reshape(self.ne, self.nloc)[:, 0].reshape(nz, ny, nx)
+            Jx = J[g][:self.nJx].reshape(nz, ny, nx + 1, nf)[..., 0]
+            pd = np.zeros((nz, ny, nx + 1)); pd[..., 0] = -phi[..., 0]; pd[..., -1] = phi[..., -1]
+            pd[..., 1:-1] = phi[..., :-1] - phi[..., 1:]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                self.Dh[0][g] = np.where(np.abs(pd) > 1e-14, Jx / pd - self.Dt[0][g], 0.0)
+
+    def cmfd_matrix(self, g):
+        nx, ny, nz = self.nx, self.ny, self.nz
+        idx = np.arange(self.ne).reshape(nz, ny, nx)
+        area = [np.einsum("k,j,i->kji", self.hz, self.hy, np.ones(nx)), np.einsum("k,j,i->kji", self.hz, np.ones(ny), self.hx),
+                np.einsum("k,j,i->kji", np.ones(nz), self.hy, self.hx)]
+        diag = (self.C[g].reshape(self.ne, self.nloc)[:, 0]).reshape(nz, ny, nx).copy()
+        rows, cols, vals = [], [], []
+        for d in range(self.dim):
+            ax = 2 - d
+            De = np.moveaxis(self.Dt[d][g] + self.Dh[d][g], ax, 0); A = np.moveaxis(area[d], ax, 0); I = np.moveaxis(idx, ax, 0)
+            dg = np.moveaxis(diag, ax, 0)
+            dg += (De[:-1] + De[1:]) * A
+            rows += [I[1:].ravel(), I[:-1].ravel()]; cols += [I[:-1].ravel(), I[1:].ravel()]
+            vals += [(-De[1:-1] * A[1:]).ravel(), (-De[1:-1] * A[:-1]).ravel()]
+        rows.append(idx.ravel()); cols.append(idx.ravel()); vals.append(diag.ravel())
+        return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.ne, self.ne))
+
+    def cmfd_correction(self, g, tf, keff, omega=1.0):
+        M = self.cmfd_matrix(g)
+        b = self.Chi[g] * tf.reshape(self.ne, self.nloc)[:, 0] / keff
+        x = np.zeros(self.ne); its = 0
+        b2 = b @ b
+        if b2 > 0:
+            thr = max(1e-16 * b2, np.finfo(float).tiny)
+            r = b.copy()
+            dg = M.diagonal(); inv = np.where(dg != 0, 1.0 / np.where(dg != 0, dg, 1.0), 1.0)
+            p = inv * r; an = r @ p
+            for its in range(1, 101):
+                t = M @ p; al = an / (p @ t); x += al * p; r -= al * t
+                if r @ r < thr: break
+                z = inv * r; ao, an = an, r @ z; p = z + (an / ao) * p
+        pc = self.phi[g * self.nPhi:(g + 1) * self.nPhi].reshape(self.ne, self.nloc)[:, 0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = np.where(np.abs(pc) > 1e-14, np.clip(x / pc, 0.5, 2.0), 1.0)
+        self.cmfd_its = its
+        return np.repeat(omega * ratio + (1 - omega), self.nloc)
+
+    def solve_keff(self, use_coarse=False, factors=(), use_diag=False, use_cmfd=False, omega=1.0):   # NeutFEM.cpp:1627-1815
         ng, nP, ne = self.ng, self.nPhi, self.ne
+        if use_cmfd: self.cmfd_init()
         k = self.keff if self.valid else 1.0
         if use_coarse and len(factors):
             k, self.phi = self.solve_coarse(factors)
@@ -241,12 +304,16 @@ class RefScipy:
                 if use_diag: x, its = Sinv[g] * rhs, 0
                 else: x, its = self.cg(g, rhs)
                 self.phi[g * nP:(g + 1) * nP] = x; cgs.append(its)
+            if use_cmfd and it >= 2:                             # :1750-1761 (J = -A^-1 B^T phi, solvers.cpp:227-228)
+                self.cmfd_dhat([-self.lu[g].solve(self.BT @ self.phi[g * nP:(g + 1) * nP]) for g in range(ng)])
+                for g in range(ng):
+                    self.phi[g * nP:(g + 1) * nP] *= self.cmfd_correction(g, tf, k, omega)
             prod_new = sum((self.Mf[g] * self.phi[g * nP:(g + 1) * nP]).sum() for g in range(ng))
             kn = k * prod_new / prod_old; dk = abs(kn - k)
             if it >= 1: k = kn
             nsq = self.phi @ self.phi; dphi = np.sqrt(((self.phi - old) ** 2).sum() / nsq)
             self.phi /= np.sqrt(nsq)
-            if it >= 2:                                          # solvers.cpp:720-756
+            if it >= 2 and not use_cmfd:                         # solvers.cpp:720-756
                 if cit == 15: cit, p0, p1 = 0, None, None
                 if cit == 0: p0 = self.phi.copy()
                 elif cit == 1: p1 = p0 + ca[1] * (self.phi - p0); self.phi = p1.copy()

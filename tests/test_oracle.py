@@ -95,6 +95,43 @@ def test_oracle_vs_scipy_operator_and_solve(shape, rt, p):
     assert rel_l2(o.phi_dofs().ravel(), r.phi) < 1e-8
 
 
+@pytest.mark.parametrize("shape,rt,p,ng,tol", [((9, 1, 1), 0, 0, 2, 1e-10), ((4, 3, 3), 1, 1, 1, 1e-6), ((8, 7, 1), 0, 0, 2, 1e-5)])
+def test_oracle_cmfd_vs_scipy(shape, rt, p, ng, tol):
+    """CMFD (src/NeutFEM.cpp:662-1017): the C oracle (matrix-free 7-point operator) against an explicit scipy matrix with
+    Eigen's preconditioned CG written out in numpy; D-tilde exact, first corrections to the conditioning of the CMFD matrix"""
+    inp = synthetic_inputs(*shape, ng=ng, seed=3, dirichlet=(1, 2, 3, 5))
+    o, r = _pair(inp, rt, p)
+    t = (1e-9, 1e-9, 1e-9, 4, 2000)
+    o.set_tol(*t); r.set_tol(*t)
+    ko = o.SolveKeff(False, [], False, True); kr = r.solve_keff(use_cmfd=True)
+    assert abs(ko - kr) / kr < tol and rel_l2(o.phi_dofs().ravel(), r.phi) < 50 * tol
+    for g in range(ng):
+        for d in range(o.dim):
+            dt, dh = o.cmfd_coefficients(g, d)
+            assert np.abs(dt - r.Dt[d][g].ravel()).max() < 1e-14 * np.abs(dt).max()
+            if d: assert not dh.any()                             # only x faces get a D-hat (:866-867)
+    assert np.abs(o.cmfd_coefficients(0, 0)[1]).max() > 0.1
+
+
+def test_cmfd_full_path_is_rounding_chaotic():
+    """Why full-solver CMFD parity cannot be tight: on the oracle ALONE, tightening the inner CG tolerance from 1e-11 to
+    1e-13 (a ~1e-12 perturbation of phi, see the no-CMFD column) moves the flux after the first CMFD correction by
+    O(0.1): D~ + D^ is negative with the full solver's Sol_J_ sign, and CG runs 100 iterations on an indefinite matrix."""
+    inp = synthetic_inputs(12, 12, 6, 1, seed=3, dirichlet=(1, 2, 3, 5))
+    out = {}
+    for cm in (False, True):
+        for tl in (1e-11, 1e-13):
+            o = make_oracle(inp); o.set_linear_solver(6); o.set_tol(1e-9, tl, 1e-9, 3, 5000)
+            o.SolveKeff(False, [], False, cm); out[cm, tl] = o.phi_dofs().ravel().copy()
+    assert rel_l2(out[False, 1e-11], out[False, 1e-13]) < 1e-10
+    assert rel_l2(out[True, 1e-11], out[True, 1e-13]) > 1e-3
+    # the diagonal solver's J sign keeps the operator definite: same perturbation size in, same size out
+    for tl in (1e-11, 1e-13):
+        o = make_oracle(inp); o.set_tol(1e-9, tl, 1e-9, 3, 5000); o.get_D()[...] *= 1.0 + (1e-12 if tl == 1e-11 else 0.0); o.BuildMatrices()
+        o.SolveKeff(False, [], True, True); out["d", tl] = o.phi_dofs().ravel().copy()
+    assert rel_l2(out["d", 1e-11], out["d", 1e-13]) < 1e-9
+
+
 def test_oracle_vs_scipy_iaea2d_with_coarse_init():
     inp = load_inputs("iaea2d")
     inp = {k: (v[..., ::2, ::2] if k in ("D", "SigR", "NSF", "Chi", "SigS") else v) for k, v in inp.items()}   # 19x19 assemblies
