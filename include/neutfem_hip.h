@@ -142,6 +142,9 @@ int nf_profile_get(nf_handle h, const char *name, long *count, double *total_ms)
 int nf_profile_reset(nf_handle h);
 /* times `reps` back-to-back Schur applies on group g (random x) with HIP events; average ms per apply */
 int nf_time_schur_apply(nf_handle h, int g, int reps, double *avg_ms);
+/* HBM microbenchmark: `reps` device-to-device streaming copies of `bytes` (read + write counted) -> GB/s; the
+ * roofline is reported against the 8 TB/s spec and against this measured figure */
+int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
 
 /* tuning knobs (no reference counterpart): "s_tx" lanes per block row, "s_seg" cells per register segment and
  * "s_pair" (0/1: two columns per thread, 16-byte accesses) of the y/z line kernels; "cg_batch" CG iterations

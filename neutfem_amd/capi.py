@@ -15,7 +15,7 @@ SYMBOLS = [
     "nf_comm_init", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
-    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply",
+    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy",
     "nf_set_option", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
 
@@ -74,6 +74,7 @@ def load():
     L.nf_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long), dp]
     L.nf_profile_reset.argtypes = [vp]
     L.nf_time_schur_apply.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.nf_time_device_copy.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.nf_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.nf_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.nf_dev_free.argtypes = [vp, vp]
@@ -261,6 +262,9 @@ class HipSolver:
     def time_schur_apply(self, g, reps):
         ms = C.c_double(); self._chk(self.L.nf_time_schur_apply(self.h, g, reps, C.byref(ms))); return ms.value
 
+    def time_device_copy(self, nbytes, reps=20):
+        v = C.c_double(); self._chk(self.L.nf_time_device_copy(self.h, int(nbytes), reps, C.byref(v))); return v.value
+
 
 def device_count():
     return load().nf_device_count()
@@ -325,8 +329,8 @@ class HipTeam:
     def build(self):
         for s in self.slabs: s.build()
 
-    def solve_keff(self, use_coarse=False, factors=(), profile=False):
-        return self.head.solve_keff(use_coarse, factors, False, profile)
+    def solve_keff(self, use_coarse=False, factors=(), profile=False, use_diag=False):
+        return self.head.solve_keff(use_coarse, factors, use_diag, profile)
 
     def history(self): return self.head.history()
     def profile(self, name): return self.head.profile(name)

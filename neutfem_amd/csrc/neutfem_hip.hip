@@ -82,6 +82,8 @@ struct nf_team {
     std::vector<nf_solver *> slabs;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;   // interface planes travel here while the x / y passes run on `stream`
+    hipEvent_t ev_z1 = nullptr, ev_xchg = nullptr;
     int nproc = 1, rank = 0;
     ncclComm_t comm = nullptr;
     bool rccl_reduce = false;       // scalar reductions go through ncclAllReduce (nproc > 1, or forced for testing)
@@ -248,6 +250,9 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
     dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red);
+    if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
+    if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
+    if (T->ev_xchg) (void)hipEventDestroy(T->ev_xchg);
     if (T->stream) (void)hipStreamDestroy(T->stream);
     delete T;
 }
@@ -305,6 +310,10 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
             rc = fail(NF_ERR_HIP, "nf_create: upload failed");
     };
     if (hipStreamCreateWithFlags(&T->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(NF_ERR_HIP, "hipStreamCreate failed");
+    if (rc == NF_OK && (if_lo || if_hi)) {
+        if (hipStreamCreateWithFlags(&T->comm_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T->ev_z1, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&T->ev_xchg, hipEventDisableTiming) != hipSuccess) rc = fail(NF_ERR_HIP, "comm stream / event creation failed");
+    }
     up(&S->d_hx, S->hx); up(&S->d_hy, S->hy); up(&S->d_hz, S->hz); up(&S->d_xb, S->xb); up(&S->d_yb, S->yb); up(&S->d_zb, S->zb);
     const size_t NN = (size_t)S->nphi * ng;
     if (rc == NF_OK) rc = dalloc(&S->d_phi, NN);
@@ -535,7 +544,7 @@ static void prof_collect(nf_team *T)
 // exchange one plane per interface: own c_hi goes up (becomes the upper slab's r_lo), own c_lo goes down.
 // which = 0: the per-apply contributions (d_clo/d_chi -> d_rlo/d_rhi); which = 1: the separator-diagonal halves of
 // group g (d_hlo/d_hhi -> d_rlo/d_rhi, build time).
-static int exchange_planes(nf_team *T, int which, int g)
+static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
 {
     const int ns = (int)T->slabs.size();
     auto send_lo = [&](nf_solver *S) { return which == 0 ? S->d_clo : S->d_hlo + (size_t)g * S->nlines[2]; };
@@ -543,20 +552,20 @@ static int exchange_planes(nf_team *T, int which, int g)
     for (int i = 0; i + 1 < ns; ++i) {                            // interfaces between local slabs
         nf_solver *A = T->slabs[i], *B = T->slabs[i + 1];
         const size_t bytes = (size_t)A->nlines[2] * sizeof(double);
-        HIPCHK(hipMemcpyAsync(B->d_rlo, send_hi(A), bytes, hipMemcpyDeviceToDevice, T->stream));
-        HIPCHK(hipMemcpyAsync(A->d_rhi, send_lo(B), bytes, hipMemcpyDeviceToDevice, T->stream));
+        HIPCHK(hipMemcpyAsync(B->d_rlo, send_hi(A), bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(A->d_rhi, send_lo(B), bytes, hipMemcpyDeviceToDevice, st));
     }
     nf_solver *bot = T->slabs.front(), *top = T->slabs.back();
     if (T->nproc > 1 && (bot->if_lo || top->if_hi)) {
         const size_t cnt = (size_t)bot->nlines[2];
         NCCLCHK(g_rccl.GroupStart());
         if (bot->if_lo) {
-            NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, T->stream));
-            NCCLCHK(g_rccl.Recv(bot->d_rlo, cnt, NCCL_DOUBLE, T->rank - 1, T->comm, T->stream));
+            NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
+            NCCLCHK(g_rccl.Recv(bot->d_rlo, cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
         }
         if (top->if_hi) {
-            NCCLCHK(g_rccl.Send(send_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, T->stream));
-            NCCLCHK(g_rccl.Recv(top->d_rhi, cnt, NCCL_DOUBLE, T->rank + 1, T->comm, T->stream));
+            NCCLCHK(g_rccl.Send(send_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
+            NCCLCHK(g_rccl.Recv(top->d_rhi, cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
         }
         NCCLCHK(g_rccl.GroupEnd());
     } else if (bot->if_lo || top->if_hi) {
@@ -575,7 +584,7 @@ static int team_prepare(nf_team *T)
     if (any) {
         const int ng = T->slabs[0]->ng;
         for (int g = 0; g < ng; ++g) {
-            NFCHK(exchange_planes(T, 1, g));
+            NFCHK(exchange_planes(T, 1, g, T->stream));
             for (auto *S : T->slabs) {
                 const long nl = S->nlines[2];
                 const unsigned gr = (unsigned)((nl + 255) / 256);
@@ -710,10 +719,15 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
             NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, cg, nullptr, 1));
         }
         if (T->profile) (void)hipEventRecord(b, T->stream);
-        NFCHK(exchange_planes(T, 0, 0));
+        // the planes travel on the comm stream while the x and y passes run; the z pass waits for them (ev_xchg)
+        HIPCHK(hipEventRecord(T->ev_z1, T->stream));
+        HIPCHK(hipStreamWaitEvent(T->comm_stream, T->ev_z1, 0));
+        NFCHK(exchange_planes(T, 0, 0, T->comm_stream));
+        HIPCHK(hipEventRecord(T->ev_xchg, T->comm_stream));
     }
     for (int d = 0; d < dim; ++d) {
         const int last = d == dim - 1;
+        if (d == 2 && any_if) HIPCHK(hipStreamWaitEvent(T->stream, T->ev_xchg, 0));
         if (T->profile) prof_begin(T, d, &a, &b);
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
@@ -832,22 +846,35 @@ int nf_solve_group(nf_handle S, int g, const double *rhs_dev, double *phi_dev, d
 }
 
 // ---- diagonal cache ----------------------------------------------------------------------------
+// Whole team at once: on slabs the interface faces need the neighbour's edge-cell a2 (one plane per group, exchanged here).
 int nf_build_diagonal_cache(nf_handle S)
 {
     if (!S) return fail(NF_ERR_ARG, "null handle");
-    if (!S->built) return fail(NF_ERR_STATE, "nf_build_diagonal_cache: call nf_build first");
-    if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh");
+    nf_team *T = S->team;
+    for (auto *X : T->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_build_diagonal_cache: call nf_build first");
     if (S->k != 0 || S->m != 0) return NF_OK;                     // "non applicable (ordre > 0)", src/NeutFEM.cpp:484-487
-    if (S->diag_valid) return NF_OK;
+    bool valid = true, any_if = false;
+    for (auto *X : T->slabs) { valid &= X->diag_valid; any_if |= X->if_lo || X->if_hi; }
+    if (valid) return NF_OK;
     HIPCHK(hipSetDevice(S->device));
-    const long N = S->N;
-    NFCHK(dalloc(&S->d_Sinv, (size_t)N * S->ng));
-    Geom G = make_geom(S);
-    for (int g = 0; g < S->ng; ++g)
-        hipLaunchKernelGGL(k_diag_cache, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, S->team->stream, G, S->d_D + g * N, S->d_Cd + g * N, S->d_Sinv + g * N, N);
+    for (auto *X : T->slabs) NFCHK(dalloc(&X->d_Sinv, (size_t)X->N * X->ng));
+    for (int g = 0; g < S->ng; ++g) {
+        if (any_if) {
+            for (auto *X : T->slabs) {
+                const long nl = X->nlines[2];
+                hipLaunchKernelGGL(k_edge_a2, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, T->stream, make_geom(X), X->d_D + g * X->N, X->d_clo, X->d_chi, nl);
+            }
+            NFCHK(exchange_planes(T, 0, 0, T->stream));
+        }
+        for (auto *X : T->slabs) {
+            const long N = X->N;
+            hipLaunchKernelGGL(k_diag_cache, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, T->stream, make_geom(X), X->d_D + g * N, X->d_Cd + g * N,
+                               X->d_Sinv + g * N, N, X->if_lo ? X->d_rlo : (const double *)nullptr, X->if_hi ? X->d_rhi : (const double *)nullptr);
+        }
+        HIPCHK(hipStreamSynchronize(T->stream));                  // the exchange buffers are reused by the next group
+    }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(S->team->stream));
-    S->diag_valid = true;
+    for (auto *X : T->slabs) X->diag_valid = true;
     return NF_OK;
 }
 int nf_get_diagonal_cache(nf_handle S, int g, double *sinv_host)
@@ -1136,7 +1163,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     const bool single = team_is_single(T);
     NFCHK(team_prepare(T));
     int use_diag = (o->use_diagonal_solver && S0->k == 0 && S0->m == 0) ? 1 : 0;   // flag dropped for order > 0 (:1640-1644)
-    if (use_diag) { if (!single) return fail(NF_ERR_UNSUPPORTED, "the diagonal-Schur path is not available on a slab-decomposed mesh"); NFCHK(nf_build_diagonal_cache(S0)); }
+    if (use_diag) NFCHK(nf_build_diagonal_cache(S0));         // whole team; slabs exchange one edge plane per group
     const bool use_cmfd = o->use_cmfd != 0;
     if (use_cmfd) {                                               // :1655-1658
         if (!single) return fail(NF_ERR_UNSUPPORTED, "CMFD is not available on a slab-decomposed mesh");
@@ -1404,6 +1431,30 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
     float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *avg_ms = ms / reps;
+    return NF_OK;
+}
+
+int nf_time_device_copy(nf_handle S, size_t bytes, int reps, double *gbps)
+{
+    if (!S || bytes < 16 || reps < 1 || !gbps) return fail(NF_ERR_ARG, "nf_time_device_copy: bad arguments");
+    HIPCHK(hipSetDevice(S->device));
+    hipStream_t st = S->team->stream;
+    const long n2 = (long)(bytes / 16);
+    double2 *a = nullptr, *b = nullptr;
+    NFCHK(dalloc(&a, (size_t)n2)); if (dalloc(&b, (size_t)n2) != NF_OK) { dfree(a); return NF_ERR_HIP; }
+    (void)hipMemsetAsync(a, 0, (size_t)n2 * 16, st);
+    const int grid = 256 * 16;                                    // 16 blocks per CU
+    hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, st, a, b, n2);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, st, a, b, n2);
+    (void)hipEventRecord(e1, st);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dfree(a); dfree(b);
+    if (e != hipSuccess) return fail(NF_ERR_HIP, "nf_time_device_copy: %s", hipGetErrorString(e));
+    *gbps = 2.0 * (double)n2 * 16.0 * reps / (ms * 1e-3) / 1e9;   // read + write
     return NF_OK;
 }
 

@@ -292,8 +292,19 @@ __global__ void k_sred_inv(const double *__restrict__ own, const double *__restr
 }
 
 // BuildDiagonalSchurCache (src/NeutFEM.cpp:483-597): S_inv(e) = 1/(C_ee + sum_faces B_ef^2 / A_ff)
+// Slabs: the A_ff of an interface z face sums the edge cells of both slabs; nb_lo / nb_hi hold the neighbour's a2 per
+// z line (k_edge_a2, exchanged once per group at cache-build time), nullptr on a domain boundary.
+__global__ void k_edge_a2(Geom G, const double *__restrict__ D, double *__restrict__ lo, double *__restrict__ hi, long nlines)
+{
+    const long line = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (line >= nlines) return;
+    const int ix = (int)(line % G.nx), iy = (int)(line / G.nx);
+    double a2, a1;
+    cell_a(G, 2, ix, iy, 0, D[line], a2, a1); lo[line] = a2;
+    cell_a(G, 2, ix, iy, G.nz - 1, D[(long)(G.nz - 1) * G.nx * G.ny + line], a2, a1); hi[line] = a2;
+}
 __global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double *__restrict__ Cd,
-                             double *__restrict__ Sinv, long N)
+                             double *__restrict__ Sinv, long N, const double *__restrict__ nb_lo, const double *__restrict__ nb_hi)
 {
     const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (e >= N) return;
@@ -312,11 +323,13 @@ __global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double 
         if (c > 0) {
             int jx = ix - (d == 0), jy = iy - (d == 1), jz = iz - (d == 2);
             cell_a(G, d, jx, jy, jz, D[e - sl], b2n, b1n); Alo += b2n;
-        } else if (G.dir_lo[d]) Alo += dirichlet_term(G, d, ix, iy, iz, D[e]);
+        } else if (d == 2 && nb_lo) Alo += nb_lo[e % nxy];
+        else if (G.dir_lo[d]) Alo += dirichlet_term(G, d, ix, iy, iz, D[e]);
         if (c + 1 < n) {
             int jx = ix + (d == 0), jy = iy + (d == 1), jz = iz + (d == 2);
             cell_a(G, d, jx, jy, jz, D[e + sl], b2n, b1n); Ahi += b2n;
-        } else if (G.dir_hi[d]) Ahi += dirichlet_term(G, d, ix, iy, iz, D[e]);
+        } else if (d == 2 && nb_hi) Ahi += nb_hi[e % nxy];
+        else if (G.dir_hi[d]) Ahi += dirichlet_term(G, d, ix, iy, iz, D[e]);
         if (fabs(G.T0 * Alo) > 1e-14) S += b2 / Alo;
         if (fabs(G.T0 * Ahi) > 1e-14) S += b2 / Ahi;
     }
@@ -1034,6 +1047,12 @@ __global__ void k_cmfd_correct(const double *__restrict__ x, double *__restrict_
     if (fabs(pc) > 1e-14) { ratio = x[e] / pc; ratio = fmax(0.5, fmin(2.0, ratio)); }
     const double corr = omega * ratio + (1.0 - omega) * 1.0;
     for (int l = 0; l < nloc; ++l) phi[l * N + e] *= corr;
+}
+
+// streaming copy (HBM microbenchmark for the roofline's "of measured copy" figure): 16-byte accesses, fixed grid
+__global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, long n2)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += gridDim.x * 256L) dst[i] = src[i];
 }
 
 // fill with a deterministic pseudo-random pattern (profiling helper)

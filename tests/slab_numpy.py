@@ -122,6 +122,26 @@ class SlabOperator:
         if self.if_hi: uf[m] = u_hi
         return beta * (uf[1:] - uf[:-1])
 
+    def diag_sinv(self):
+        """BuildDiagonalSchurCache (src/NeutFEM.cpp:483-597) on a slab: S_inv = 1/(C + sum_faces B^2/A_ff); the A_ff of an
+        interface z face needs the neighbour's edge a2 -- one plane exchanged once (what nf_build_diagonal_cache does)"""
+        S = self.C.copy()
+        for d in range(3):
+            ax = 2 - d
+            a2 = np.moveaxis(self.a2[d], ax, 0)
+            Aff = np.zeros((a2.shape[0] + 1,) + a2.shape[1:]); Aff[:-1] += a2; Aff[1:] += a2
+            lo, hi = self.dir[d]
+            if d == 2 and (self.if_lo or self.if_hi):
+                r_lo, r_hi = self.comm.exchange(a2[0] if self.if_lo else None, a2[-1] if self.if_hi else None)
+                if self.if_lo: Aff[0] += r_lo
+                else: Aff[0] += lo
+                if self.if_hi: Aff[-1] += r_hi
+                else: Aff[-1] += hi
+            else:
+                Aff[0] += lo; Aff[-1] += hi
+            S += np.moveaxis(self.beta ** 2 / Aff[:-1] + self.beta ** 2 / Aff[1:], 0, ax)
+        return 1.0 / S
+
     def apply(self, x):
         y = self.C * x + self._line_apply(x, 0) + self._line_apply(x, 1)
         if self.if_lo or self.if_hi:

@@ -53,17 +53,20 @@ def _worker(rank, world, port, shape, seed, out):
     rng = np.random.default_rng(5)
     xg = rng.standard_normal((nz, ny, nx)); bg = np.abs(rng.standard_normal((nz, ny, nx)))
     y = op.apply(xg[k0:k1])
+    sinv = op.diag_sinv()
     x, its = distributed_cg(op, bg[k0:k1], 1e-10, 2000, GlooComm(rank, world))
     # gather on rank 0 and compare with the undivided oracle
-    ys = [None] * world; xs = [None] * world
-    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(x, xs if rank == 0 else None)
+    ys = [None] * world; xs = [None] * world; ss = [None] * world
+    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(x, xs if rank == 0 else None); dist.gather_object(sinv, ss if rank == 0 else None)
     tmax = torch.tensor([float(rank + 1)], dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
         o = make_oracle(inp)
         o.set_tol(1e-5, 1e-10, 1e-5, 10, 2000)
         yo = o.schur_apply(0, xg.ravel()); xo, _, its_o = o.solve_group(0, bg.ravel())
         ya = np.concatenate(ys).ravel(); xa = np.concatenate(xs).ravel()
-        np.save(out, np.array([np.linalg.norm(ya - yo) / np.linalg.norm(yo), np.linalg.norm(xa - xo) / np.linalg.norm(xo), its, its_o, tmax.item()]))
+        so = o.diag_cache(0); sa = np.concatenate(ss).ravel()
+        np.save(out, np.array([np.linalg.norm(ya - yo) / np.linalg.norm(yo), np.linalg.norm(xa - xo) / np.linalg.norm(xo), its, its_o, tmax.item(),
+                               np.abs(sa / so - 1).max()]))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -75,12 +78,13 @@ def _free_port():
 def test_slab_partition_method_gloo(world, shape, tmp_path):
     out = str(tmp_path / "res.npy")
     mp.spawn(_worker, args=(world, _free_port(), shape, 11, out), nprocs=world, join=True)
-    err_apply, err_solve, its, its_o, tmax = np.load(out)
+    err_apply, err_solve, its, its_o, tmax, err_sinv = np.load(out)
     # 2 slabs: exact for any thickness.  3 slabs: the middle slab (33 planes) is thick enough that its two separators
     # decouple to rounding (0.268^32); thinner middle slabs are refused by the HIP path (test_gpu_slabs.py)
     assert err_apply < 1e-12, err_apply
     assert err_solve < 1e-8 and abs(its - its_o) <= max(2, 0.05 * its_o)
     assert tmax == world                       # max-over-ranks reduction used for the bench timing
+    assert err_sinv < 1e-13                    # diagonal-Schur cache on slabs (one edge plane per interface)
 
 
 def test_split_planes():

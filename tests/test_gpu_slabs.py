@@ -110,3 +110,21 @@ def test_team_coarse_init_matches_undivided():
     with pytest.raises(RuntimeError, match="do not divide"):
         t.solve_keff(True, [2, 2, 5])
     s.close(); t.close()
+
+
+@pytest.mark.parametrize("planes", [[(0, 5), (5, 12)], [(0, 32), (32, 64), (64, 96)]])
+def test_team_diagonal_path_matches_oracle(planes):
+    """diagonal-Schur path on slabs: one edge plane of a2 per interface at cache-build time, then only the
+    per-outer scalars; S_inv per slab and the whole power iteration against the undivided oracle"""
+    nz = planes[-1][1]
+    inp = synthetic_inputs(11, 9, nz, 2, seed=17, dirichlet=(1, 2, 4, 5, 6))
+    o, t = make_oracle(inp), make_team(inp, planes)
+    tol = (1e-10, 1e-10, 1e-10, 500, 1000)
+    o.set_tol(*tol); t.set_tol(*tol)
+    ko = o.SolveKeff(False, [], True); kt, n = t.solve_keff(use_diag=True)
+    assert n == o.info("last_outer") and abs(kt - ko) / ko < 1e-12
+    assert rel_l2(t.get_phi_local().ravel(), o.phi_dofs().reshape(2, nz, 9, 11).ravel()) < 1e-11
+    for g in range(2):
+        sinv = np.concatenate([s.diagonal_cache(g) for s in t.slabs])
+        assert np.abs(sinv / o.diag_cache(g) - 1).max() < 1e-14
+    t.close()
