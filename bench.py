@@ -232,7 +232,12 @@ def main():
     # the same fraction against what a plain streaming copy reaches on this very GPU ("of spec" and "of measured copy")
     copy_gbs = head.time_device_copy(1 << 30, 20)
     roofline["measured_copy"] = dict(GBps=round(copy_gbs, 1), frac_of_copy=round(ach / copy_gbs, 4),
-                                     schur_apply_frac_of_copy=round(roofline["schur_apply"]["achieved"] / copy_gbs, 4))
+                                     schur_apply_frac_of_copy=round(roofline["schur_apply"]["achieved"] / copy_gbs, 4),
+                                     note="best of plain / nontemporal copy kernels and hipMemcpyDtoD, 1 GiB, read + write counted; "
+                                          "fractions use ALGORITHMIC bytes, which exceed the HBM traffic (PMC) of these kernels")
+    if traffic:
+        tg = traffic / (dom["avg_ms"] * 1e-3) / 1e9
+        roofline["measured_copy"].update(hbm_traffic_GBps=round(tg, 1), hbm_traffic_frac_of_copy=round(tg / copy_gbs, 4))
 
     out = dict(metric="outer power-iters/sec (IAEA-3D RT0-P0 k-eigenvalue solve)", value=round(a.steps / dt, 4), unit="outer-iters/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,

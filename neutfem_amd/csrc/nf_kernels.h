@@ -1049,10 +1049,27 @@ __global__ void k_cmfd_correct(const double *__restrict__ x, double *__restrict_
     for (int l = 0; l < nloc; ++l) phi[l * N + e] *= corr;
 }
 
-// streaming copy (HBM microbenchmark for the roofline's "of measured copy" figure): 16-byte accesses, fixed grid
+// streaming copy (HBM microbenchmark for the roofline's "of measured copy" figure): 16-byte accesses, 4 independent
+// loads in flight per thread; NT = nontemporal loads / stores (no reuse, keeps L2 / MALL out of the way)
+template <bool NT>
 __global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, long n2)
 {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += gridDim.x * 256L) dst[i] = src[i];
+    const long stride = gridDim.x * 256L;
+    long i = blockIdx.x * 256L + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (NT) { v[u].x = __builtin_nontemporal_load(&src[i + u * stride].x); v[u].y = __builtin_nontemporal_load(&src[i + u * stride].y); }
+            else v[u] = src[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (NT) { __builtin_nontemporal_store(v[u].x, &dst[i + u * stride].x); __builtin_nontemporal_store(v[u].y, &dst[i + u * stride].y); }
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n2; i += stride) dst[i] = src[i];
 }
 
 // fill with a deterministic pseudo-random pattern (profiling helper)

@@ -80,3 +80,17 @@ def test_error_behaviour():
     with pytest.raises(RuntimeError, match="x-line kernel limit"):
         t.schur_apply(0, np.zeros(t.n_phi))
     t.close()
+
+
+@pytest.mark.parametrize("nx,rt", [(1500, 0), (2100, 0), (3000, 0), (700, 1)])
+def test_long_x_lines(nx, rt):
+    """x lines beyond 1024 cells (NCH = 16 / 32 chunks per lane; RT1 up to 1024): apply and group solve against the oracle"""
+    inp = synthetic_inputs(nx, 3, 1, 1, seed=nx, dirichlet=(1, 2, 3))
+    o, s = make_oracle(inp, rt, rt), make_hip(inp, rt, rt)
+    x = np.random.default_rng(2).standard_normal(o.n_phi)
+    assert rel_l2(s.schur_apply(0, x), o.schur_apply(0, x)) < 1e-12
+    b = np.abs(x)
+    o.set_tol(1e-5, 1e-10, 1e-5, 10, 4000)
+    xo, _, io = o.solve_group(0, b); xs, is_, _ = s.solve_group(0, b, 1e-10, 4000)
+    assert rel_l2(xs, xo) < 1e-7 and abs(is_ - io) <= max(3, 0.03 * io)
+    s.close()
