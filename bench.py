@@ -201,11 +201,17 @@ def main():
     nJd = {0: (nxl + 1) * nyl * nzl, 1: nxl * (nyl + 1) * nzl, 2: nxl * nyl * (nzl + 1)}
     kern = {0: "k_schur_x<2,NCH,VEC>", 1: "k_schur_s<SEG,1> (y lines)", 2: "k_schur_s<SEG,2> (z lines)"}
     passes = []
+    # fused CG (undivided RT0-P0 mesh): the x pass also carries x_sol += alpha p and p = r + beta p of the previous
+    # iteration (read r, x_sol; write p, x_sol = 32 B/cell on top of the apply; p itself is read once for both jobs) on every
+    # CG iteration but the first of a group solve
+    n_solves = hist["cg"].size
+    fused_bytes = 32.0 * Nl * (1.0 - n_solves / max(float(hist["cg"].sum()), 1.0)) if slabs_total == 1 else 0.0
     for d, nm in enumerate(["schur_x", "schur_y", "schur_z"][:dim]):
         c, ms = s.profile(nm)
         if c:
             per = a.loopback_slabs                                  # launches per timed pass (one per local slab)
-            passes.append(dict(name=nm, kernel=kern[d], launches=c * per, avg_ms=ms / c / per, alg_bytes=algorithmic_bytes(dim, Nl, nJd[d])))
+            passes.append(dict(name=nm, kernel=kern[d], launches=c * per, avg_ms=ms / c / per,
+                               alg_bytes=algorithmic_bytes(dim, Nl, nJd[d]) + (fused_bytes if d == 0 else 0.0)))
     dom = max(passes, key=lambda p: p["avg_ms"])
     # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     # command, gfx950 x2 read correction; profiles/r01_pmc_traffic_256cube.json).  Per-cell figure x cells of this run.
@@ -220,10 +226,10 @@ def main():
         traffic = None
     ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
     ca, cms = s.profile("schur_apply")
-    apply_bytes = (24.0 * Nl + 40.0 * sum(nJd[d] for d in range(dim))) * a.loopback_slabs
+    apply_bytes = (24.0 * Nl + 40.0 * sum(nJd[d] for d in range(dim))) * a.loopback_slabs + fused_bytes
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
-                    alg_bytes_per_launch=dom["alg_bytes"],
+                    alg_bytes_per_launch=dom["alg_bytes"], fused_cg_vector_bytes_in_x_pass=fused_bytes,
                     schur_apply=dict(avg_ms=round(cms / max(ca, 1), 4), alg_bytes=apply_bytes,
                                      achieved=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9, 1),
                                      frac=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),

@@ -103,6 +103,8 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
+    CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (see k_schur_x)
+    int opt_fuse = 1;
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
 
@@ -634,8 +636,9 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const bool vec = (S->nx % 2 == 0);
     hipStream_t st = S->team->stream;
     const double *L = S->d_L[0] + g * N, *DR = S->d_DR[0] + g * N, *D0 = S->d_D0[0] + g * S->nlines[0];
-    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg);
-    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg);
+    const CgFuse fz = S->team->fuse;
+    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
+    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
 }
 template <int NB>
 static int launch_x_nb(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts)
@@ -804,27 +807,39 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     CgScalars sc; memset(&sc, 0, sizeof sc);
     int launched = 0;
     int batch = T->cg_batch > 0 ? T->cg_batch : std::max(1, T->last_its[g] - 1);
-    while (launched < maxit) {
+    // fused variant (RT0-P0, undivided mesh): x_sol / p updates ride in the next x pass (k_schur_x, CgFuse)
+    const bool fused = T->opt_fuse && team_is_single(T) && T->slabs[0]->nloc == 1;
+    if (fused) T->fuse = CgFuse{ T->slabs[0]->d_p, T->slabs[0]->d_r, x[0] };
+    int rc = NF_OK;
+    while (launched < maxit && rc == NF_OK) {
         int nb = std::min(batch, maxit - launched);
-        for (int it = 0; it < nb; ++it) {
-            NFCHK(team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt));
-            NFCHK(team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0));
+        for (int it = 0; it < nb && rc == NF_OK; ++it) {
+            rc = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
+            if (rc == NF_OK) rc = team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0);
+            if (rc != NF_OK) break;
             for (int i = 0; i < ns; ++i) {
                 nf_solver *S = T->slabs[i];
-                hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
+                if (fused) hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
+                else hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
             }
-            NFCHK(team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0));
+            rc = team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0);
+            if (fused) continue;
             for (int i = 0; i < ns; ++i) {
                 nf_solver *S = T->slabs[i];
                 hipLaunchKernelGGL(k_cg_pupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_p, S->d_r, S->nphi, T->d_cg);
             }
         }
+        if (rc != NF_OK) break;
         launched += nb;
-        HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
-        HIPCHK(hipStreamSynchronize(T->stream));
+        if (hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream) != hipSuccess || hipStreamSynchronize(T->stream) != hipSuccess) {
+            rc = fail(NF_ERR_HIP, "CG: reading the device scalars failed"); break;
+        }
         if (sc.done) break;
         batch = T->cg_batch > 0 ? T->cg_batch : (launched < 8 ? 1 : 2);
     }
+    T->fuse = CgFuse{ nullptr, nullptr, nullptr };
+    NFCHK(rc);
+    if (fused) hipLaunchKernelGGL(k_cg_flush, dim3(gcnt[0]), dim3(256), 0, T->stream, x[0], (const double *)T->slabs[0]->d_p, T->slabs[0]->nphi, T->d_cg);
     if (launched == 0) {
         HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
         HIPCHK(hipStreamSynchronize(T->stream));
@@ -1478,6 +1493,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_seg")) T->opt_s_seg = (int)value;
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
+    else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
 }

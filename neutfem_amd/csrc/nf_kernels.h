@@ -19,7 +19,8 @@ namespace nf {
 // device-resident state of one CG solve (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636)
 struct CgScalars {
     double rr, pAp, alpha, beta, rr_new, tol_sq, rhs_norm, tol;
-    int done, its, maxit, pad;
+    int done, its, maxit;
+    int pend;      // fused CG only: the x += alpha p of the last FIN_RR has not been applied yet (k_schur_x / k_cg_flush do it)
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -56,15 +57,17 @@ __device__ __forceinline__ void cg_logic(int op, const double *tot, int nq, CgSc
         cg->rhs_norm = sqrt(tot[0]);
         cg->tol = tol;
         cg->tol_sq = tol * tol * cg->rhs_norm * cg->rhs_norm;
-        cg->done = 0; cg->its = 0; cg->maxit = maxit;
+        cg->done = 0; cg->its = 0; cg->maxit = maxit; cg->pend = 0;
         if (maxit <= 0) cg->done = 1;
     } else if (op == FIN_PAP) {                // src/solvers.cpp:602-606
         cg->pAp = tot[0];
+        cg->pend = 0;                          // the x pass of this iteration has applied the deferred update
         if (fabs(tot[0]) < 1e-30) cg->done = 1;
         else cg->alpha = cg->rr / tot[0];
     } else if (op == FIN_RR) {                 // src/solvers.cpp:613-631
         cg->rr_new = tot[0];
         cg->its += 1;
+        cg->pend = 1;
         if (tot[0] < cg->tol_sq) { cg->rr = tot[0]; cg->done = 1; }
         else {
             cg->beta = tot[0] / cg->rr;
@@ -346,11 +349,16 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
     if (vec) { double2 v = make_double2(0, 0); if (ok) v = *reinterpret_cast<const double2 *>(p + i); a = v.x; b = v.y; }
     else { a = ok ? p[i] : 0.0; b = ok2 ? p[i + 1] : 0.0; }
 }
+// Fused CG (RT0-P0, undivided mesh): the vector updates that follow FIN_RR -- x_sol += alpha p and p = r + beta p
+// (src/solvers.cpp:609,630) -- are deferred to the next iteration's x pass, which reads p anyway: p is read once instead
+// of three times per iteration and one launch disappears.  Same operands, same expressions: bit-identical iterates.
+// The last iteration's x_sol update is applied by k_cg_flush (CgScalars::pend).
+struct CgFuse { double *p; const double *r; double *xsol; };
 template <int K, int NCH, bool VEC, int NB>
 __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                                                  const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
                                                  int first, int last, double *__restrict__ partials,
-                                                 const CgScalars *__restrict__ cg)
+                                                 const CgScalars *__restrict__ cg, CgFuse fz)
 {
     static_assert(K == 2, "two cells per lane and chunk");
     __shared__ double sred[4];
@@ -363,6 +371,8 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const doub
     const long base = lv ? line * nx : 0;
     const int iy = lv ? (int)(line % ny) : 0, iz = lv ? (int)(line / ny) : 0;
     double xm[NB + 1][NCH][K], yo[NB + 1][NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], xL[NCH][K], xR[NCH][K], ic[NCH][K];
+    const bool fuse = NB == 0 && fz.p != nullptr && cg->its > 0;
+    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
@@ -373,6 +383,20 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const doub
         for (int q = 0; q <= NB; ++q) {
             ld2(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
             ld2(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
+        }
+        if (NB == 0 && fuse) {
+            double r0, r1, s0, s1;
+            ld2(fz.r, base + c0, ok, VEC, r0, r1, ok2);
+            ld2(fz.xsol, base + c0, ok, VEC, s0, s1, ok2);
+            s0 += f_alpha * xm[0][ch][0]; s1 += f_alpha * xm[0][ch][1];
+            xm[0][ch][0] = r0 + f_beta * xm[0][ch][0]; xm[0][ch][1] = r1 + f_beta * xm[0][ch][1];
+            if (VEC) {
+                if (ok) { *reinterpret_cast<double2 *>(fz.xsol + base + c0) = make_double2(s0, s1);
+                          *reinterpret_cast<double2 *>(fz.p + base + c0) = make_double2(xm[0][ch][0], xm[0][ch][1]); }
+            } else {
+                if (ok) { fz.xsol[base + c0] = s0; fz.p[base + c0] = xm[0][ch][0]; }
+                if (ok2) { fz.xsol[base + c0 + 1] = s1; fz.p[base + c0 + 1] = xm[0][ch][1]; }
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -662,6 +686,28 @@ __global__ __launch_bounds__(256) void k_cg_update(double *__restrict__ x, doubl
     }
     s = block_sum(s, sred);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// fused CG: r -= alpha q and |r|^2 only (x_sol and p are updated by the next x pass)
+__global__ __launch_bounds__(256) void k_cg_rupdate(double *__restrict__ r, const double *__restrict__ q, long n,
+                                                    const CgScalars *__restrict__ cg, double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    if (cg->done) return;
+    const double alpha = cg->alpha;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const double rn = r[i] - alpha * q[i];
+        r[i] = rn; s += rn * rn;
+    }
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// fused CG: the x_sol update of the final iteration
+__global__ void k_cg_flush(double *__restrict__ x, const double *__restrict__ p, long n, const CgScalars *__restrict__ cg)
+{
+    if (!cg->pend) return;
+    const double alpha = cg->alpha;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] += alpha * p[i];
 }
 __global__ __launch_bounds__(256) void k_cg_pupdate(double *__restrict__ p, const double *__restrict__ r, long n,
                                                     const CgScalars *__restrict__ cg)

@@ -73,9 +73,9 @@ def test_error_behaviour():
     s.close()
     with pytest.raises(RuntimeError, match="out of range"):
         HipSolver(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], device=99)
-    long_x = np.linspace(0, 1, 1100)
+    long_x = np.linspace(0, 1, 4100)                               # beyond the 4096-cell x-line limit of the RT0 kernel
     t = HipSolver(0, 0, 1, long_x, np.linspace(0, 1, 3), np.array([0.0]))
-    t.upload_xs(np.ones((1, 2, 1099)), np.ones((1, 2, 1099)), np.ones((1, 2, 1099)), np.ones((1, 2, 1099)), np.zeros((1, 1, 2, 1099)))
+    t.upload_xs(np.ones((1, 2, 4099)), np.ones((1, 2, 4099)), np.ones((1, 2, 4099)), np.ones((1, 2, 4099)), np.zeros((1, 1, 2, 4099)))
     t.build()
     with pytest.raises(RuntimeError, match="x-line kernel limit"):
         t.schur_apply(0, np.zeros(t.n_phi))
