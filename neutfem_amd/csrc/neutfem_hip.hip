@@ -806,7 +806,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
     CgScalars sc; memset(&sc, 0, sizeof sc);
     int launched = 0;
-    int batch = T->cg_batch > 0 ? T->cg_batch : std::max(1, T->last_its[g] - 1);
+    int batch = T->cg_batch > 0 ? T->cg_batch : std::max(1, T->last_its[g] - 1), grow = 2;
     // fused variant (RT0-P0, undivided mesh): x_sol / p updates ride in the next x pass (k_schur_x, CgFuse)
     const bool fused = T->opt_fuse && team_is_single(T) && T->slabs[0]->nloc == 1;
     if (fused) T->fuse = CgFuse{ T->slabs[0]->d_p, T->slabs[0]->d_r, x[0] };
@@ -835,7 +835,10 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             rc = fail(NF_ERR_HIP, "CG: reading the device scalars failed"); break;
         }
         if (sc.done) break;
-        batch = T->cg_batch > 0 ? T->cg_batch : (launched < 8 ? 1 : 2);
+        // after the first (predicted) batch grow geometrically: an iteration launched past convergence is five early-exit
+        // kernels (~10 us), a host check is a D2H copy + stream drain (~50 us)
+        batch = T->cg_batch > 0 ? T->cg_batch : (launched < 8 ? 1 : grow);
+        if (launched >= 8) grow = std::min(64, 2 * grow);
     }
     T->fuse = CgFuse{ nullptr, nullptr, nullptr };
     NFCHK(rc);
