@@ -120,6 +120,12 @@ def split_planes(nz, parts):
     return [(cuts[i], cuts[i + 1]) for i in range(parts)]
 
 
+def note(msg):
+    """progress line on stderr (long set-ups must not look hung)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,11 +170,16 @@ def main():
         N_local = sum(x.ne for x in s.slabs); ng, dim = head.ng, head.dim
         N = a.n * a.n * nz
     else:
+        note(f"building case {a.case} n={a.n}")
         case = cases.iaea3d_resampled(a.n) if a.case == "iaea3d" else cases.synthetic_checkerboard(a.n, a.groups)
+        note("uploading + BuildMatrices")
         s = make_solver(case, local)
+        note("built")
         head = s
         N, ng, dim = s.ne, s.ng, s.dim
-    TOL_FLUX = 1e-4                                             # drivers: set_tol(1e-5,1e-4,1e-4,200,1000)
+    TOL_FLUX, MAX_INNER = 1e-4, 1000                            # drivers: set_tol(1e-5,1e-4,1e-4,200,1000)
+    if a.case == "checker":                                     # fixed work, exactly 50 CG iterations per group solve
+        TOL_FLUX, MAX_INNER = 0.0, 50
 
     def barrier():
         if dist is not None:
@@ -177,10 +188,11 @@ def main():
 
     # warm-up: W untimed outer iterations (also warms caches / clocks); state carries over like the reference
     if a.warmup > 0:
-        s.set_tol(0.0, TOL_FLUX, 1e-4, a.warmup, 1000)
+        s.set_tol(0.0, TOL_FLUX, 1e-4, a.warmup, MAX_INNER)
         s.solve_keff()
-    s.set_tol(0.0, TOL_FLUX, 1e-4, a.steps, 1000)               # tol_keff = 0 -> exactly K outers
+    s.set_tol(0.0, TOL_FLUX, 1e-4, a.steps, MAX_INNER)          # tol_keff = 0 -> exactly K outers
     s.profile_reset()
+    note("timed steps")
     barrier(); t0 = time.perf_counter()
     k_timed, n_out = s.solve_keff(profile=True)
     barrier(); dt = time.perf_counter() - t0
@@ -249,7 +261,8 @@ def main():
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=(f"IAEA-3D resampled {a.n}x{a.n}x{nz} RT0-P0 2g" if a.case == "iaea3d" else case["name"]) +
-                           ", full Schur path, CG tol 1e-4, Chebyshev", cells=int(N), groups=int(ng),
+                           (", full Schur path, CG tol 1e-4, Chebyshev" if a.case == "iaea3d" else ", full Schur path, exactly 50 CG iterations per group solve, Chebyshev"),
+                           cells=int(N), groups=int(ng),
                            cg_iters_per_outer=round(cg_per_outer, 1),
                            parallelism=f"{world} process(es) x {a.loopback_slabs} z-slab(s) each; RCCL: interface planes + scalar all-reduces"),
                roofline=roofline, keff_after_timed_steps=k_timed)
