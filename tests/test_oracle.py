@@ -171,6 +171,38 @@ def test_literature_keff_sanity():
         assert abs(1e5 * (1 / kref - 1 / run["keff"])) < 10.0
 
 
+def _refined(inp, r):
+    out = dict(inp)
+    for k in ("D", "SigR", "NSF", "Chi", "SigS"):
+        out[k] = np.ascontiguousarray(np.repeat(np.repeat(inp[k], r, axis=-1), r, axis=-2))
+    for k in ("x_breaks", "y_breaks"):
+        b = inp[k]; out[k] = np.interp(np.arange((len(b) - 1) * r + 1) / r, np.arange(len(b)), b)
+    return out
+
+
+@pytest.mark.parametrize("name,kref,final_pct,final_pcm", [("iaea2d", 1.029585, 1.6, 1.5), ("koeberg2d", 1.007954, 0.7, 7.5)])
+def test_oracle_converges_to_the_drivers_power_tables(name, kref, final_pct, final_pcm):
+    """The fixtures the reference's own drivers hold for this path: k_ref and the published assembly-power tables
+    (tests/iaea2d/iaea2d.py:479-504 with the normalisation of :418-420, tests/koeberg2d/koeberg2d.py:553-576; data in
+    tests/golden/assembly_powers.json).  RT0-P0 on the drivers' 2x2 / 4x4 / 8x8 meshes: the oracle's assembly powers and k
+    converge monotonically onto them (IAEA-2D 8x8: 1.4 % max power error, -0.7 pcm)."""
+    import json, os
+    tab = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "assembly_powers.json")))[name]
+    ref = np.array([[np.nan if v is None else v for v in r] for r in tab["table"]]); na = ref.shape[0]
+    base = load_inputs(name)
+    errs, pcms = [], []
+    for r in (1, 2, 4):
+        inp = _refined(base, r) if r > 1 else base
+        o = make_oracle(inp, 0, 0); o.set_linear_solver(6); o.set_tol(1e-7, 1e-6, 1e-6, 300, 2000)
+        k = o.SolveKeff(True, [2, 2, 1])
+        pv = (inp["NSF"] * o.get_flux()).sum(axis=0)               # the drivers' pvol (iaea2d.py:408-415)
+        nm = pv.shape[0] // na
+        F = pv.reshape(na, nm, na, nm).sum(axis=1).sum(axis=2); F = tab["normalisation"] * F / F.sum()
+        errs.append(np.nanmax(np.abs(100.0 * (ref - F) / ref))); pcms.append(abs(1e5 * (1 / kref - 1 / k)))
+    assert errs[0] > errs[1] > errs[2] and pcms[0] > pcms[1] > pcms[2]
+    assert errs[2] < final_pct and pcms[2] < final_pcm
+
+
 def test_reference_quirks():
     inp = load_inputs("iaea2d")
     o = make_oracle(inp)
