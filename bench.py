@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--n", type=int, default=256, help="cells per axis of the resampled IAEA-3D mesh")
     ap.add_argument("--case", default="iaea3d", choices=["iaea3d", "checker"])
     ap.add_argument("--groups", type=int, default=8, help="groups of the synthetic checkerboard case")
-    ap.add_argument("--cpu-sample-iters", type=int, default=6, help="CG iterations timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample-iters", type=int, default=12, help="CG iterations timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed converged solve (k-eff, pcm)")
     ap.add_argument("--no-parity", action="store_true", help="skip the small-mesh GPU-vs-oracle parity probe")
     ap.add_argument("--no-small", action="store_true", help="skip the small BASELINE configs (0-2)")

@@ -57,6 +57,47 @@ def test_schur_linearity_and_symmetry_large():
     s.close()
 
 
+def test_full_size_256cube_properties():
+    """BASELINE config 3 at full size (IAEA-3D resampled to 256^3, 16.8 M cells, the bench workload), where the oracle is not
+    run: size-independent properties.  S_g is linear, symmetric and positive definite; the 2-slab partition-method apply
+    equals the undivided one; a CG solve really leaves |S x - b| <= tol |b| (checked with a separate apply); and one power
+    iteration keeps the Rayleigh-quotient identity k_new = k * sum(M_f phi_new) / sum(M_f phi_old) (src/NeutFEM.cpp:1766-1774)."""
+    from bench import make_solver
+    from neutfem_amd import cases
+    from neutfem_amd.capi import HipTeam
+    case = cases.iaea3d_resampled(256)
+    s = make_solver(case, 0)
+    n = s.n_phi
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    for g in range(2):
+        Sx, Sy, Sxy = s.schur_apply(g, x), s.schur_apply(g, y), s.schur_apply(g, 2.0 * x - 3.0 * y)
+        assert rel_l2(Sxy, 2.0 * Sx - 3.0 * Sy) < 1e-12
+        assert abs(y @ Sx - x @ Sy) <= 1e-10 * abs(y @ Sx)
+        assert x @ Sx > 0
+    b = np.abs(y)
+    xs, its, res = s.solve_group(0, b, 1e-6, 3000)
+    assert 0 < its < 3000 and res < 1e-6
+    assert np.linalg.norm(s.schur_apply(0, xs) - b) < 1.05e-6 * np.linalg.norm(b)
+    # one outer iteration from the flat flux: k stays frozen on outer 0 (:1774) and the history records |k_new - k|
+    s.set_tol(0.0, 1e-4, 1e-4, 1, 1000)
+    k, n_out = s.solve_keff()
+    h = s.history()
+    assert n_out == 1 and k == 1.0 and h["dk"][0] > 0 and np.isfinite(h["dphi"][0])
+    phi = s.get_phi()
+    assert np.isfinite(phi).all() and abs(np.linalg.norm(phi) - 1.0) < 1e-12          # normalised iterate (:1780-1784)
+    s.close()
+    # the same operator cut into two z-slabs (partition method, loopback on this GPU)
+    t = HipTeam(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], case["z_breaks"], [(0, 128), (128, 256)])
+    t.set_linear_solver(6)
+    for a_, ty in case["bc"]:
+        t.set_bc(a_, ty)
+    t.upload_xs_global(case["D"], case["SigR"], case["NSF"], case["Chi"], case["SigS"]); t.build()
+    yt = t.schur_apply(1, x.reshape(256, 256, 256))
+    assert rel_l2(yt.ravel(), Sx) < 1e-12                         # Sx = group 1 from the loop above
+    t.close()
+
+
 @pytest.mark.parametrize("name", ["iaea2d", "iaea3d_1x1", "zion2d"])
 def test_cg_solve_group(name):
     inp = load_inputs(name)
