@@ -148,10 +148,10 @@ def main():
         allp = split_planes(nz, slabs_total)
         mine = allp[rank * a.loopback_slabs:(rank + 1) * a.loopback_slabs]
         k0, k1 = mine[0][0], mine[-1][1]
-        case = cases.iaea3d_resampled(a.n, z_range=(k0, k1)) if a.case == "iaea3d" else None
-        if case is None:
-            raise SystemExit("bench.py: the slab-decomposed run supports --case iaea3d")
-        zb_full = np.linspace(0.0, 380.0, nz + 1)
+        if a.case == "iaea3d":
+            case = cases.iaea3d_resampled(a.n, z_range=(k0, k1)); zb_full = np.linspace(0.0, 380.0, nz + 1)
+        else:
+            case = cases.synthetic_checkerboard(a.n, a.groups, z_range=(k0, k1)); zb_full = case["z_breaks"]
         s = capi.HipTeam(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], zb_full, mine, device=local,
                          below=rank > 0, above=rank < world - 1)
         s.set_linear_solver(6)

@@ -32,12 +32,14 @@ def iaea3d_resampled(n, nz=None, z_range=None):
                 name=f"IAEA-3D resampled {n}x{n}x{nz} RT0-P0 2g")
 
 
-def synthetic_checkerboard(n, ng=8):
-    """SURVEY.md 8d C5 (h = 1 cm, material id ((ix>>4)+(iy>>4)+(iz>>4))&1, 0 = fuel, 1 = moderator)."""
+def synthetic_checkerboard(n, ng=8, z_range=None):
+    """SURVEY.md 8d C5 (h = 1 cm, material id ((ix>>4)+(iy>>4)+(iz>>4))&1, 0 = fuel, 1 = moderator).
+    z_range = (k0, k1): only those z-planes of the XS arrays (slab-decomposed runs); z_breaks stay global."""
     brk = np.linspace(0.0, float(n), n + 1)
     i = np.arange(n) >> 4
-    mod = ((i[:, None, None] + i[None, :, None] + i[None, None, :]) & 1).astype(bool)
-    shp = (n, n, n)
+    k0, k1 = z_range if z_range is not None else (0, n)
+    mod = ((i[k0:k1, None, None] + i[None, :, None] + i[None, None, :]) & 1).astype(bool)
+    shp = (k1 - k0, n, n)
     D = np.empty((ng,) + shp); SigR = np.empty((ng,) + shp); NSF = np.zeros((ng,) + shp); Chi = np.zeros((ng,) + shp)
     SigS = np.zeros((ng, ng) + shp)
     chi = [0.60, 0.30, 0.08, 0.02] + [0.0] * 60
