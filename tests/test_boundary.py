@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.SYMBOLS) == declared, "neutfem_amd/capi.py and include/neutfem_hip.h disagree"
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/neutfem_hip.h compiles as C99 with -pedantic and examples/solve_keff.c links against the shared library;
+    without a GPU the program reports the library's own error (no CPU fallback) and exits 2"""
+    import subprocess
+    import neutfem_amd
+    exe = str(tmp_path / "solve_keff")
+    libdir = os.path.dirname(neutfem_amd.lib_path())
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "solve_keff.c"), "-L" + libdir, "-lneutfem_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.check_call(cmd)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if r.returncode == 2:
+        assert "no HIP device" in r.stderr
+    else:
+        assert r.returncode == 0 and r.stdout.startswith("k-eff = ")
+
+
 def test_no_cpu_fallback():
     from neutfem_amd import capi
     if capi.device_count() > 0:
