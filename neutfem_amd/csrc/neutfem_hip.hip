@@ -1044,7 +1044,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     if (rc == NF_OK) {
         nf_keff_opts co = *o;                                    // :2460-2467
         co.tol_keff = o->tol_keff * 10.0; co.tol_flux = o->tol_flux * 10.0; co.max_outer = o->max_outer / 2;
-        co.use_coarse_init = 0; co.n_coarse_factors = 0; co.use_diagonal_solver = 0; co.solver_type_pushed = 1; co.profile = 0;
+        co.use_coarse_init = 0; co.n_coarse_factors = 0; co.use_diagonal_solver = 0; co.solver_type_pushed = 1; co.profile = 0; co.use_cmfd = 0;
         rc = solve_keff_impl(CT, &co, &kc, &nout);
     }
     if (rc == NF_OK) {

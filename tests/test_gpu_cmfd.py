@@ -154,3 +154,17 @@ def test_cmfd_refused_on_slabs():
     with pytest.raises(RuntimeError, match="slab"):
         t.head.solve_keff(use_cmfd=True)
     t.close()
+
+
+def test_diagonal_cmfd_with_coarse_init():
+    """the fastest advertised combination, src/wrapper.cpp:663: SolveKeff(True, factors, use_diagonal_solver=True, use_cmfd=True)
+    (the coarse solve itself runs the full Schur path without CMFD, src/NeutFEM.cpp:2460-2467).  On a problem where the CMFD
+    map contracts, so that the CG-tolerance-level difference of the two coarse starts is not amplified."""
+    inp = synthetic_inputs(12, 12, 6, 2, seed=3, dirichlet=(1, 2, 3, 5))
+    o, s = _pair(inp, tol=1e-10, max_outer=300)
+    ko = o.SolveKeff(True, [2, 2, 2], True, True); ks, n = s.solve_keff(True, [2, 2, 2], use_diag=True, use_cmfd=True)
+    ho, hs = o.history(), s.history()
+    assert abs(n - ho["n_outer"]) <= 1 and hs["coarse_outer"] == ho["coarse_outer"] > 0
+    assert abs(ks - ko) / ko < 1e-8
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-7
+    s.close()
