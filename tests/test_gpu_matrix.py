@@ -1,0 +1,43 @@
+"""Every combination of SolveKeff's flags (src/wrapper.cpp:598-603, docstring :655-663) x solver-type plumbing x cold / warm
+call, on the device against the oracle: k, outer counts, coarse outer counts, flux."""
+import numpy as np
+import pytest
+
+from helpers import make_oracle, rel_l2, synthetic_inputs
+from neutfem_amd.capi import HipSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(inp, pushed):
+    o = make_oracle(inp)
+    s = HipSolver(0, 0, int(inp["ng"]), inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    if pushed:
+        o.set_linear_solver(6); s.set_linear_solver(6)             # BICGSTAB -> implicit Schur CG at tol_flux
+    for a, t in zip(inp["bc_attr"], inp["bc_type"]):
+        s.set_bc(int(a), int(t))
+    s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"]); s.build()
+    return o, s
+
+
+@pytest.mark.parametrize("pushed", [True, False])
+@pytest.mark.parametrize("cmfd", [False, True])
+@pytest.mark.parametrize("diag", [False, True])
+@pytest.mark.parametrize("coarse", [False, True])
+def test_solvekeff_flag_matrix(coarse, diag, cmfd, pushed):
+    full_cmfd = cmfd and not diag                                 # rounding-chaotic map (tests/test_gpu_cmfd.py): first correction only
+    shape = (8, 6, 1) if full_cmfd else (12, 12, 6)
+    inp = synthetic_inputs(*shape, ng=2, seed=3, dirichlet=(1, 2, 3, 5))
+    o, s = _pair(inp, pushed)
+    tol = (1e-10, 1e-10, 1e-10, 3 if full_cmfd else 300, 3000)
+    o.set_tol(*tol); s.set_tol(*tol)
+    f = [2, 2, 1] if shape[2] == 1 else [2, 2, 2]
+    for call in range(2):                                         # second call: warm flux, warm k (has_valid_keff_), D-hat carried over
+        ko = o.SolveKeff(coarse, f, diag, cmfd); ks, n = s.solve_keff(coarse, f, use_diag=diag, use_cmfd=cmfd)
+        ho, hs = o.history(), s.history()
+        assert hs["coarse_outer"] == ho["coarse_outer"] and (ho["coarse_outer"] > 0) == coarse
+        assert abs(n - ho["n_outer"]) <= (0 if not coarse else 1), (n, ho["n_outer"])
+        lim = 2e-6 if full_cmfd else 1e-8
+        assert abs(ks - ko) / ko < lim, (call, ks, ko)
+        assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 20 * lim
+    s.close()
