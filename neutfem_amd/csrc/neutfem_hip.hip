@@ -675,7 +675,8 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const long nxy = (long)S->nx * S->ny;
     const long sl = d == 1 ? S->nx : nxy, ostride = d == 1 ? nxy : S->nx;
     const int nouter = d == 1 ? S->nz : S->ny;
-    int SEG = T->opt_s_seg ? T->opt_s_seg : (S->nb > 0 ? (n <= 256 ? 4 : 8) : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
+    // 8-cell segments up to 1024 cells per line (16 / 32 cells spill to scratch: 1.4x slower even though TX drops to 8 at 1024)
+    int SEG = T->opt_s_seg ? T->opt_s_seg : (S->nb > 0 ? (n <= 256 ? 4 : 8) : (n <= 1024 ? 8 : (n <= 2048 ? 16 : 32)));
     int NSEG = (n + SEG - 1) / SEG;
     if (NSEG > 128) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit", n);
     int TX = T->opt_s_tx ? T->opt_s_tx : 64;
