@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=256, help="cells per axis of the resampled IAEA-3D mesh")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("NEUTFEM_BENCH_N", "256")),
+                    help="cells per axis of the resampled IAEA-3D mesh (env NEUTFEM_BENCH_N: torch.distributed.run's own parser chokes on --n)")
     ap.add_argument("--case", default="iaea3d", choices=["iaea3d", "checker"])
     ap.add_argument("--groups", type=int, default=8, help="groups of the synthetic checkerboard case")
     ap.add_argument("--cpu-sample-iters", type=int, default=12, help="CG iterations timed on the CPU oracle (0 = skip)")
@@ -130,6 +131,7 @@ def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("NEUTFEM_FORCE_DEVICE", local))   # tests: several ranks on the one GPU of the box (tests/test_gpu_multiproc.py)
     from neutfem_amd import capi, cases                       # loads libneutfem_hip.so (and with it the ROCm HIP runtime) first
     if capi.device_count() <= 0:
         raise SystemExit("bench.py: no HIP device visible -- the hot path has no CPU fallback")

@@ -57,7 +57,7 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 static Rccl g_rccl;
-static const int NCCL_DOUBLE = 8, NCCL_SUM = 0;       // ncclFloat64 / ncclSum in rccl.h
+static const int NCCL_DOUBLE = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclFloat64 / ncclSum / ncclMax in rccl.h
 #define NCCLCHK(x) do { int r_ = (x); if (r_ != 0) return fail(NF_ERR_HIP, "%s failed: %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); } while (0)
 
 static int rccl_load()
@@ -92,6 +92,7 @@ struct nf_team {
     double *d_out = nullptr;        // 4 doubles read by the host each outer
     double *d_red = nullptr;        // 4 doubles: process-local sums awaiting the all-reduce
     bool linked_ready = false;      // separator diagonals exchanged
+    int sep_sweeps = 0;             // Jacobi sweeps on the separator system (0: slabs thick enough for it to be diagonal to rounding)
     std::vector<int> last_its;
     // stats of the last SolveKeff
     int last_outer = 0, coarse_outer = 0; long last_cg_total = 0;
@@ -136,6 +137,7 @@ struct nf_solver {
     double *d_alo = nullptr, *d_ahi = nullptr, *d_hlo = nullptr, *d_hhi = nullptr, *d_gfl = nullptr;   // ng * nlines[2]
     double *d_sinv_lo = nullptr, *d_sinv_hi = nullptr;  // ng * nlines[2]
     double *d_clo = nullptr, *d_chi = nullptr, *d_rlo = nullptr, *d_rhi = nullptr, *d_ulo = nullptr, *d_uhi = nullptr;
+    double *d_ctlo = nullptr, *d_cthi = nullptr, *d_elo = nullptr, *d_ehi = nullptr, *d_relo = nullptr, *d_rehi = nullptr;   // separator sweeps (thin slabs)
     // state
     double *d_phi = nullptr, *d_raw = nullptr;          // current iterate / raw group solutions, ng*N
     double *d_p0 = nullptr, *d_p1 = nullptr;            // Chebyshev history
@@ -327,7 +329,7 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     if (rc == NF_OK) rc = dalloc(&S->d_q, S->nphi);
     if (rc == NF_OK && (if_lo || if_hi)) {
         const size_t nl = (size_t)S->nlines[2];
-        double **arrs[] = { &S->d_clo, &S->d_chi, &S->d_rlo, &S->d_rhi, &S->d_ulo, &S->d_uhi };
+        double **arrs[] = { &S->d_clo, &S->d_chi, &S->d_rlo, &S->d_rhi, &S->d_ulo, &S->d_uhi, &S->d_ctlo, &S->d_cthi, &S->d_elo, &S->d_ehi, &S->d_relo, &S->d_rehi };
         for (auto a : arrs) if (rc == NF_OK) { rc = dalloc(a, nl); if (rc == NF_OK) (void)hipMemset(*a, 0, nl * sizeof(double)); }
     }
     if (rc == NF_OK) rc = team_alloc(T);
@@ -363,6 +365,7 @@ int nf_destroy(nf_handle S)
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
+    dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
     dfree(S->d_phi); dfree(S->d_raw); dfree(S->d_p0); dfree(S->d_p1);
     dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q);
     if (T) {
@@ -544,18 +547,21 @@ static void prof_collect(nf_team *T)
 
 // ---- communication between slabs -----------------------------------------------------------------
 // exchange one plane per interface: own c_hi goes up (becomes the upper slab's r_lo), own c_lo goes down.
-// which = 0: the per-apply contributions (d_clo/d_chi -> d_rlo/d_rhi); which = 1: the separator-diagonal halves of
+// which = 0: the per-apply contributions (d_clo/d_chi -> d_rlo/d_rhi); which = 2: the separator-sweep couplings
+// (d_elo/d_ehi -> d_relo/d_rehi); which = 1: the separator-diagonal halves of
 // group g (d_hlo/d_hhi -> d_rlo/d_rhi, build time).
 static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
 {
     const int ns = (int)T->slabs.size();
-    auto send_lo = [&](nf_solver *S) { return which == 0 ? S->d_clo : S->d_hlo + (size_t)g * S->nlines[2]; };
-    auto send_hi = [&](nf_solver *S) { return which == 0 ? S->d_chi : S->d_hhi + (size_t)g * S->nlines[2]; };
+    auto send_lo = [&](nf_solver *S) { return which == 0 ? S->d_clo : which == 2 ? S->d_elo : S->d_hlo + (size_t)g * S->nlines[2]; };
+    auto send_hi = [&](nf_solver *S) { return which == 0 ? S->d_chi : which == 2 ? S->d_ehi : S->d_hhi + (size_t)g * S->nlines[2]; };
+    auto recv_lo = [&](nf_solver *S) { return which == 2 ? S->d_relo : S->d_rlo; };
+    auto recv_hi = [&](nf_solver *S) { return which == 2 ? S->d_rehi : S->d_rhi; };
     for (int i = 0; i + 1 < ns; ++i) {                            // interfaces between local slabs
         nf_solver *A = T->slabs[i], *B = T->slabs[i + 1];
         const size_t bytes = (size_t)A->nlines[2] * sizeof(double);
-        HIPCHK(hipMemcpyAsync(B->d_rlo, send_hi(A), bytes, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(A->d_rhi, send_lo(B), bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(recv_lo(B), send_hi(A), bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(recv_hi(A), send_lo(B), bytes, hipMemcpyDeviceToDevice, st));
     }
     nf_solver *bot = T->slabs.front(), *top = T->slabs.back();
     if (T->nproc > 1 && (bot->if_lo || top->if_hi)) {
@@ -563,11 +569,11 @@ static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
         NCCLCHK(g_rccl.GroupStart());
         if (bot->if_lo) {
             NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
-            NCCLCHK(g_rccl.Recv(bot->d_rlo, cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
+            NCCLCHK(g_rccl.Recv(recv_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
         }
         if (top->if_hi) {
             NCCLCHK(g_rccl.Send(send_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
-            NCCLCHK(g_rccl.Recv(top->d_rhi, cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
+            NCCLCHK(g_rccl.Recv(recv_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
         }
         NCCLCHK(g_rccl.GroupEnd());
     } else if (bot->if_lo || top->if_hi) {
@@ -595,7 +601,10 @@ static int team_prepare(nf_team *T)
             }
             HIPCHK(hipStreamSynchronize(T->stream));
         }
-        // separators must decouple through a slab: |a_lo a_hi (T_II^-1)[first,last]| * sqrt(sinv_lo sinv_hi) <= 1e-15
+        // separators must decouple through a slab: |a_lo a_hi (T_II^-1)[first,last]| * sqrt(sinv_lo sinv_hi) <= 1e-15.
+        // The verdict is taken on the maximum over ALL ranks, so that every process of a decomposed run refuses together
+        // (a single refusing rank would leave the others blocked in their next collective).
+        double worst = 0.0; int worst_nz = 0;
         for (auto *S : T->slabs) {
             if (!(S->if_lo && S->if_hi)) continue;
             const size_t nl = (size_t)S->nlines[2] * ng;
@@ -603,10 +612,29 @@ static int team_prepare(nf_team *T)
             HIPCHK(hipMemcpy(gfl.data(), S->d_gfl, nl * sizeof(double), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(slo.data(), S->d_sinv_lo, nl * sizeof(double), hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(shi.data(), S->d_sinv_hi, nl * sizeof(double), hipMemcpyDeviceToHost));
-            double worst = 0.0;
-            for (size_t i = 0; i < nl; ++i) worst = std::max(worst, std::fabs(gfl[i]) * std::sqrt(std::fabs(slo[i] * shi[i])));
-            if (worst > 1e-15)
-                return fail(NF_ERR_UNSUPPORTED, "slab of %d z-planes is too thin: separator coupling %.2e > 1e-15 (use slabs of >= ~30 planes)", S->nz, worst);
+            for (size_t i = 0; i < nl; ++i) {
+                const double w = std::fabs(gfl[i]) * std::sqrt(std::fabs(slo[i] * shi[i]));
+                if (w > worst) { worst = w; worst_nz = S->nz; }
+            }
+        }
+        if (T->rccl_reduce && T->nproc > 1) {
+            HIPCHK(hipMemcpyAsync(T->d_red, &worst, sizeof(double), hipMemcpyHostToDevice, T->stream));
+            NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
+            HIPCHK(hipMemcpyAsync(&worst, T->d_red, sizeof(double), hipMemcpyDeviceToHost, T->stream));
+            HIPCHK(hipStreamSynchronize(T->stream));
+        }
+        // Jacobi on the separator system contracts by <= 2 * worst per sweep (two neighbours): sweeps until the neglected term is
+        // below 1e-16 of the solution; none for thick slabs (>= ~30 planes), refused beyond 8 (slabs of fewer than ~4 planes)
+        T->sep_sweeps = 0;
+        if (worst > 1e-15) {
+            const double rho = 2.0 * worst;
+            int m = rho < 1.0 ? (int)std::ceil(std::log(1e-16) / std::log(rho)) - 1 : 99;
+            if (m < 1) m = 1;
+            if (m > 8) {
+                if (worst_nz) return fail(NF_ERR_UNSUPPORTED, "slab of %d z-planes is too thin: separator coupling %.2e needs %d sweeps (limit 8; use slabs of >= 4 planes)", worst_nz, worst, m);
+                return fail(NF_ERR_UNSUPPORTED, "a slab on another rank is too thin: separator coupling %.2e needs %d sweeps (limit 8; use slabs of >= 4 planes)", worst, m);
+            }
+            T->sep_sweeps = m;
         }
     }
     T->linked_ready = true;
@@ -729,6 +757,24 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
         HIPCHK(hipEventRecord(T->ev_z1, T->stream));
         HIPCHK(hipStreamWaitEvent(T->comm_stream, T->ev_z1, 0));
         NFCHK(exchange_planes(T, 0, 0, T->comm_stream));
+        // separator values (+ Jacobi sweeps for thin slabs), still on the comm stream, still behind the x / y passes
+        auto each_slab = [&](auto &&launch) {
+            for (int i = 0; i < ns; ++i) {
+                nf_solver *S = T->slabs[i];
+                if (S->if_lo || S->if_hi) launch(S, S->nlines[2], dim3((unsigned)((S->nlines[2] + 255) / 256)));
+            }
+        };
+        each_slab([&](nf_solver *S, long nl, dim3 gr) {
+            hipLaunchKernelGGL(k_separators, gr, dim3(256), 0, T->comm_stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi, S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl,
+                               S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, S->if_lo, S->if_hi, cg); });
+        for (int sweep = 0; sweep < T->sep_sweeps; ++sweep) {
+            each_slab([&](nf_solver *S, long nl, dim3 gr) {
+                hipLaunchKernelGGL(k_sep_couple, gr, dim3(256), 0, T->comm_stream, S->d_gfl + g * nl, S->d_ulo, S->d_uhi, S->d_elo, S->d_ehi, nl, S->if_lo, S->if_hi, cg); });
+            NFCHK(exchange_planes(T, 2, 0, T->comm_stream));
+            each_slab([&](nf_solver *S, long nl, dim3 gr) {
+                hipLaunchKernelGGL(k_sep_update, gr, dim3(256), 0, T->comm_stream, S->d_ctlo, S->d_cthi, S->d_elo, S->d_ehi, S->d_relo, S->d_rehi,
+                                   S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg); });
+        }
         HIPCHK(hipEventRecord(T->ev_xchg, T->comm_stream));
     }
     for (int d = 0; d < dim; ++d) {
@@ -745,9 +791,6 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
                 int np = 0;
                 if (d == 0) NFCHK(launch_x(S, g, ma, G, last, part, cg, &np));
                 else if (d == 2 && (S->if_lo || S->if_hi)) {
-                    const long nl = S->nlines[2];
-                    hipLaunchKernelGGL(k_separators, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, T->stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi,
-                                       S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg);
                     NFCHK(launch_s(S, 2, g, ma, G, last, part, cg, &np, 2));
                 } else NFCHK(launch_s(S, d, g, ma, G, last, part, cg, &np, 0));
                 total += np;

@@ -275,17 +275,47 @@ __global__ void k_factor_lines(Geom G, int d, const double *__restrict__ D, doub
     }
 }
 
-// separator values of the partition method: u = (own contribution + neighbour's) / S_red   (slab interfaces)
+// separator values of the partition method (slab interfaces).  The reduced system over the separators of a z line is
+//   S_red(s) u_s - G_below u_{s-1} - G_above u_{s+1} = c_s,   c_s = c_hi(slab below) + c_lo(slab above),
+// G_r = a_lo a_hi (T_II^-1)[first,last] of slab r (SlabOut::gfl) = coupling of a slab's two separators through it.  G decays
+// like 0.27^planes: for thick slabs the system is diagonal to rounding (u = c / S_red, k_separators alone); for thin slabs
+// a few Jacobi sweeps u <- (c + G_below u_{s-1} + G_above u_{s+1}) / S_red (k_sep_couple, one more neighbour exchange,
+// k_sep_update) reach rounding level; the number of sweeps is fixed at build time from the measured coupling.
+// Both sides of an interface evaluate the same expression in the same order, so their copies of u agree bitwise.
 __global__ void k_separators(const double *__restrict__ clo, const double *__restrict__ chi, const double *__restrict__ rlo,
                              const double *__restrict__ rhi, const double *__restrict__ sinv_lo, const double *__restrict__ sinv_hi,
-                             double *__restrict__ ulo, double *__restrict__ uhi, long nlines, int if_lo, int if_hi,
+                             double *__restrict__ ulo, double *__restrict__ uhi, double *__restrict__ ctlo, double *__restrict__ cthi,
+                             long nlines, int if_lo, int if_hi, const CgScalars *__restrict__ cg)
+{
+    if (cg && cg->done) return;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    if (if_lo) { const double c = rlo[i] + clo[i]; ctlo[i] = c; ulo[i] = c * sinv_lo[i]; }   // below's c_hi + own c_lo (same order on both sides)
+    if (if_hi) { const double c = chi[i] + rhi[i]; cthi[i] = c; uhi[i] = c * sinv_hi[i]; }   // own c_hi + above's c_lo
+}
+// what this slab contributes to its two separators through itself: to the upper one G u_lower, to the lower one G u_upper
+__global__ void k_sep_couple(const double *__restrict__ gfl, const double *__restrict__ ulo, const double *__restrict__ uhi,
+                             double *__restrict__ elo, double *__restrict__ ehi, long nlines, int if_lo, int if_hi,
                              const CgScalars *__restrict__ cg)
 {
     if (cg && cg->done) return;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= nlines) return;
-    if (if_lo) ulo[i] = (rlo[i] + clo[i]) * sinv_lo[i];          // below's c_hi + own c_lo (same order on both sides)
-    if (if_hi) uhi[i] = (chi[i] + rhi[i]) * sinv_hi[i];          // own c_hi + above's c_lo
+    const bool both = if_lo && if_hi;
+    if (if_hi) ehi[i] = both ? gfl[i] * ulo[i] : 0.0;
+    if (if_lo) elo[i] = both ? gfl[i] * uhi[i] : 0.0;
+}
+// u = ((c + e_from_below) + e_from_above) / S_red ; relo = the slab below's e_hi, rehi = the slab above's e_lo
+__global__ void k_sep_update(const double *__restrict__ ctlo, const double *__restrict__ cthi, const double *__restrict__ elo,
+                             const double *__restrict__ ehi, const double *__restrict__ relo, const double *__restrict__ rehi,
+                             const double *__restrict__ sinv_lo, const double *__restrict__ sinv_hi, double *__restrict__ ulo,
+                             double *__restrict__ uhi, long nlines, int if_lo, int if_hi, const CgScalars *__restrict__ cg)
+{
+    if (cg && cg->done) return;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    if (if_lo) ulo[i] = ((ctlo[i] + relo[i]) + elo[i]) * sinv_lo[i];
+    if (if_hi) uhi[i] = ((cthi[i] + ehi[i]) + rehi[i]) * sinv_hi[i];
 }
 // S_red^-1 from the two halves (own + neighbour's)
 __global__ void k_sred_inv(const double *__restrict__ own, const double *__restrict__ other, double *__restrict__ out, long n, int own_first)

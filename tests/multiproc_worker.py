@@ -1,0 +1,59 @@
+"""Worker of tests/test_gpu_multiproc.py: one rank of a slab-decomposed solve, all ranks on GPU 0, transport =
+tests/fake_rccl (NEUTFEM_RCCL_LIB).  Rendezvous and unique-id broadcast over torch.distributed/gloo, exactly as bench.py.
+usage: multiproc_worker.py <rank> <world> <port> <out.npz> <slabs_per_rank> <use_diag> <planes_per_slab>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world, port, out, per, use_diag = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+    planes = int(sys.argv[7])
+    from neutfem_amd import capi                                # HIP library first, then torch (as bench.py)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bench import split_planes
+    from helpers import synthetic_inputs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nx, ny, nz = 10, 8, planes * world * per
+    inp = synthetic_inputs(nx, ny, nz, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
+    allp = split_planes(nz, world * per)
+    mine = allp[rank * per:(rank + 1) * per]
+    k0, k1 = mine[0][0], mine[-1][1]
+    t = capi.HipTeam(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], mine, device=0, below=rank > 0, above=rank < world - 1)
+    t.set_linear_solver(6)
+    for a, ty in zip(inp["bc_attr"], inp["bc_type"]):
+        t.set_bc(int(a), int(ty))
+    t.upload_xs_global(inp["D"][:, k0:k1], inp["SigR"][:, k0:k1], inp["NSF"][:, k0:k1], inp["Chi"][:, k0:k1], inp["SigS"][:, :, k0:k1], k_offset=k0)
+    t.build()
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        idt = torch.frombuffer(bytearray(capi.HipTeam.unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(idt, 0)
+    t.comm_init(bytes(idt.numpy().tobytes()), world, rank)
+    assert t.head.info("n_ranks") == world and t.head.info("rank") == rank
+    # 1. distributed Schur apply
+    xg = np.random.default_rng(4).standard_normal((nz, ny, nx))
+    y = t.schur_apply(1, xg[k0:k1])
+    # 2. distributed power iteration (coarse-mesh start on the team, borrowed communicator)
+    import time
+    t.set_tol(1e-12, 1e-9, 1e-9, 24, 2000)                        # fixed work: 24 fine outers (12 coarse) with tight inner solves
+    t0 = time.time()
+    k, n = t.solve_keff(True, [2, 1, 2], use_diag=bool(use_diag)) if not use_diag else t.solve_keff(use_diag=True)
+    print(f"rank {rank}: k = {k:.12f} after {n} outers, {t.history()['cg'].sum()} CG iterations, {time.time() - t0:.1f} s", flush=True)
+    phi = t.get_phi_local()
+    ys = [None] * world; ps = [None] * world; ks = [None] * world
+    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n), ks if rank == 0 else None)
+    if rank == 0:
+        np.savez(out, y=np.concatenate(ys, axis=0), phi=np.concatenate(ps, axis=1), k=np.array([v[0] for v in ks]), n=np.array([v[1] for v in ks]), x=xg)
+    dist.barrier()
+    t.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

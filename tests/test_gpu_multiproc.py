@@ -1,0 +1,101 @@
+"""The REAL multi-process path on one GPU: several ranks (one process each, all on device 0) run the slab-decomposed
+Schur apply and power iteration through nf_comm_init / ncclSend / ncclRecv / ncclAllReduce, with tests/fake_rccl (a
+host-staged stand-in selected by NEUTFEM_RCCL_LIB) as the transport -- RCCL itself refuses two ranks on one device.  What
+this covers that the loopback tests cannot: rank/peer arithmetic, the order of collective calls across processes, the
+comm-stream overlap, the coarse team borrowing the communicator, and bench.py's --gpus N code path end to end."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import make_hip, make_oracle, rel_l2, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _env():
+    if not os.path.exists(FAKE):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is missing: run __graft_entry__.build()")
+    e = dict(os.environ); e["NEUTFEM_RCCL_LIB"] = FAKE; e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return e
+
+
+def _run_ranks(world, args, tmp_path, timeout=200):
+    """start `world` workers, fail fast (with every rank's output) if one exits non-zero or the run exceeds `timeout` s"""
+    import time
+    port = str(_free_port())
+    logs = [open(str(tmp_path / f"rank{r}.log"), "w+") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), port] + [str(a) for a in args],
+                              env=_env(), stdout=logs[r], stderr=subprocess.STDOUT) for r in range(world)]
+    t0 = time.time(); bad = None
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs): bad = "a rank failed"; break
+        if time.time() - t0 > timeout: bad = f"timed out after {timeout} s"; break
+        time.sleep(0.2)
+    if bad is None and any(p.returncode != 0 for p in procs): bad = "a rank failed"
+    for p in procs:
+        if p.poll() is None: p.kill()
+    out = []
+    for r, f in enumerate(logs):
+        f.seek(0); out.append(f"--- rank {r} (rc={procs[r].returncode}) ---\n" + f.read()[-3000:]); f.close()
+    return bad, "\n".join(out)
+
+
+@pytest.mark.parametrize("world,per,use_diag,planes", [(2, 1, 0, 48), (3, 1, 0, 48), (2, 2, 0, 48), (3, 1, 1, 48), (4, 1, 0, 12)])
+def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes, tmp_path):
+    """planes = 48: coarse slabs of 24 planes need one separator sweep; planes = 12: the fine slabs themselves are thin"""
+    out = str(tmp_path / "res.npz")
+    bad, logs = _run_ranks(world, [out, per, use_diag, planes], tmp_path)
+    assert bad is None, bad + "\n" + logs
+    res = np.load(out)
+    nz = planes * world * per
+    inp = synthetic_inputs(10, 8, nz, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
+    o = make_oracle(inp)
+    assert rel_l2(res["y"].ravel(), o.schur_apply(1, res["x"].ravel())) < 1e-12
+    assert np.ptp(res["k"]) == 0.0 and np.ptp(res["n"]) == 0          # every rank returns the same k and outer count
+    s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, 24, 2000)       # the same fixed work, undivided
+    ks, ns = s.solve_keff(use_diag=True) if use_diag else s.solve_keff(True, [2, 1, 2])
+    assert int(res["n"][0]) == ns == 24
+    assert abs(res["k"][0] - ks) / ks < 1e-8
+    assert rel_l2(res["phi"].ravel(), s.get_phi().ravel()) < 1e-6
+    s.close()
+
+
+def test_thin_slab_is_refused_by_every_rank(tmp_path):
+    """a middle slab of 3 planes: the refusal is taken on the all-reduced maximum, so all three ranks raise the same error at
+    the same point instead of one raising and two blocking in the next collective"""
+    bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, 0, 3], tmp_path, timeout=120)
+    assert bad == "a rank failed", (bad, logs)
+    assert logs.count("too thin") >= 3, logs
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo rendezvous, RCCL id broadcast, slab
+    split, barrier + max-over-ranks timing, one JSON line from rank 0) -- both ranks forced onto device 0"""
+    e = _env(); e["NEUTFEM_FORCE_DEVICE"] = "0"; e["NEUTFEM_BENCH_N"] = "64"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # same workload on one rank: the power iteration is the same algorithm, k after the timed steps must agree
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample-iters", "0",
+                         "--no-converge", "--no-parity", "--no-small"], env=e, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert abs(d["keff_after_timed_steps"] - d1["keff_after_timed_steps"]) / d1["keff_after_timed_steps"] < 1e-6

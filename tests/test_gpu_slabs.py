@@ -38,9 +38,27 @@ def test_team_schur_apply_matches_undivided(shape, planes):
     t.close()
 
 
-def test_thin_middle_slab_is_refused():
+@pytest.mark.parametrize("planes", [[(0, 10), (10, 20), (20, 30)], [(0, 6), (6, 11), (11, 16), (16, 21), (21, 30)], [(0, 4), (4, 8), (8, 12), (12, 30)]])
+def test_thin_slabs_use_separator_sweeps(planes):
+    """slabs too thin for the separator system to be diagonal (coupling 0.27^planes): Jacobi sweeps on it, each one more
+    neighbour exchange, bring the partition-method apply back to rounding level; the CG / power iteration follow"""
+    inp = synthetic_inputs(9, 8, 30, 2, seed=2)
+    o, t = make_oracle(inp), make_team(inp, planes)
+    rng = np.random.default_rng(4)
+    for g in range(2):
+        x = rng.standard_normal((30, 8, 9))
+        assert rel_l2(t.schur_apply(g, x).ravel(), o.schur_apply(g, x.ravel())) < 1e-12
+    tol = (1e-10, 1e-10, 1e-10, 600, 2000)
+    o.set_tol(*tol); t.set_tol(*tol)
+    ko = o.SolveKeff(); kt, n = t.solve_keff()
+    assert abs(kt - ko) / ko < 1e-9 and abs(n - o.info("last_outer")) <= 1
+    assert rel_l2(t.get_phi_local().ravel(), o.phi_dofs().reshape(2, 30, 8, 9).ravel()) < 1e-8
+    t.close()
+
+
+def test_slabs_of_three_planes_are_refused():
     inp = synthetic_inputs(8, 8, 30, 1, seed=2)
-    t = make_team(inp, [(0, 10), (10, 20), (20, 30)])
+    t = make_team(inp, [(0, 3), (3, 6), (6, 30)])
     with pytest.raises(RuntimeError, match="too thin"):
         t.schur_apply(0, np.ones((30, 8, 8)))
     t.close()
