@@ -1048,11 +1048,20 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     int rz = (nf > 2 && dim >= 3) ? std::max(o->coarse_factors[2], 1) : 1;
     // :2402-2407 -> (1.0, Sol_Phi_).  On a decomposed mesh every slab must be divisible (a global decision is needed,
     // so indivisible local slabs are an error rather than a silent fallback on some ranks only).
+    double bad = 0.0; const nf_solver *Sbad = nullptr;
     for (auto *S : T->slabs)
-        if (S->nx % rx || S->ny % ry || S->nz % rz) {
-            if (ns == 1 && T->nproc == 1) return NF_OK;
-            return fail(NF_ERR_ARG, "coarse factors (%d,%d,%d) do not divide slab %d x %d x %d", rx, ry, rz, S->nx, S->ny, S->nz);
-        }
+        if (S->nx % rx || S->ny % ry || S->nz % rz) { bad = 1.0; Sbad = S; }
+    if (T->rccl_reduce && T->nproc > 1) {                         // one verdict for all ranks (a lone refusal would block the others)
+        HIPCHK(hipMemcpyAsync(T->d_red, &bad, sizeof(double), hipMemcpyHostToDevice, T->stream));
+        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
+        HIPCHK(hipMemcpyAsync(&bad, T->d_red, sizeof(double), hipMemcpyDeviceToHost, T->stream));
+        HIPCHK(hipStreamSynchronize(T->stream));
+    }
+    if (bad != 0.0) {
+        if (ns == 1 && T->nproc == 1) return NF_OK;
+        if (Sbad) return fail(NF_ERR_ARG, "coarse factors (%d,%d,%d) do not divide slab %d x %d x %d", rx, ry, rz, Sbad->nx, Sbad->ny, Sbad->nz);
+        return fail(NF_ERR_ARG, "coarse factors (%d,%d,%d) do not divide a slab on another rank", rx, ry, rz);
+    }
     std::vector<nf_handle> C(ns, nullptr);
     int rc = NF_OK;
     for (int i = 0; i < ns && rc == NF_OK; ++i) {

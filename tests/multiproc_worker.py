@@ -20,6 +20,8 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nx, ny, nz = 10, 8, planes * world * per
+    if len(sys.argv) > 8:
+        nz = int(sys.argv[8])                                     # uneven split (e.g. 100 planes on 3 ranks = 33 / 34 / 33)
     inp = synthetic_inputs(nx, ny, nz, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
     allp = split_planes(nz, world * per)
     mine = allp[rank * per:(rank + 1) * per]

@@ -80,6 +80,14 @@ def test_thin_slab_is_refused_by_every_rank(tmp_path):
     assert logs.count("too thin") >= 3, logs
 
 
+def test_indivisible_coarse_factors_are_refused_by_every_rank(tmp_path):
+    """100 planes on 3 ranks = 33 / 34 / 33 with coarse factor 2 in z: only the outer ranks cannot coarsen, but the verdict
+    is all-reduced, so all three raise instead of the middle one blocking in the coarse solve's first collective"""
+    bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, 0, 0, 100], tmp_path, timeout=120)
+    assert bad == "a rank failed", (bad, logs)
+    assert logs.count("do not divide") >= 3, logs
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo rendezvous, RCCL id broadcast, slab
     split, barrier + max-over-ranks timing, one JSON line from rank 0) -- both ranks forced onto device 0"""
