@@ -332,6 +332,9 @@ class HipTeam:
     def solve_keff(self, use_coarse=False, factors=(), profile=False, use_diag=False):
         return self.head.solve_keff(use_coarse, factors, use_diag, profile)
 
+    def reset_flux(self):
+        for s in self.slabs: s.reset_flux()
+
     def history(self): return self.head.history()
     def profile(self, name): return self.head.profile(name)
     def profile_reset(self): self.head.profile_reset()
