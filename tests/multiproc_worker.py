@@ -43,7 +43,7 @@ def main():
     y = t.schur_apply(1, xg[k0:k1])
     # 2. distributed power iteration (coarse-mesh start on the team, borrowed communicator)
     import time
-    t.set_tol(1e-12, 1e-9, 1e-9, 24, 2000)                        # fixed work: 24 fine outers (12 coarse) with tight inner solves
+    t.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)                        # fixed work: 16 fine outers (8 coarse) with tight inner solves
     t0 = time.time()
     k, n = t.solve_keff(True, [2, 1, 2], use_diag=bool(use_diag)) if not use_diag else t.solve_keff(use_diag=True)
     print(f"rank {rank}: k = {k:.12f} after {n} outers, {t.history()['cg'].sum()} CG iterations, {time.time() - t0:.1f} s", flush=True)
