@@ -334,6 +334,7 @@ static long chain_pos(const nfo_t *h, int ix, int iy, int iz, int j)
 /* ---- constructor, src/NeutFEM.cpp:82-300, src/FEM.cpp:23-83,177-259 --------- */
 nfo_t *nfo_create(int rt_order, int p_order, int ng, int nxb, const double *xb, int nyb, const double *yb, int nzb, const double *zb)
 {
+    if (nxb < 2 || ng < 1 || !xb) return NULL;                  /* at least one cell along x (src/FEM.cpp:23-60) */
     nfo_t *h = (nfo_t *)calloc(1, sizeof(nfo_t));
     h->nxb = nxb; h->nyb = nyb; h->nzb = nzb;
     h->xb = (double *)malloc(sizeof(double) * nxb); memcpy(h->xb, xb, sizeof(double) * nxb);

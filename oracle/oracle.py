@@ -83,6 +83,8 @@ class OracleNeutFEM:
         yb = np.ascontiguousarray(y_breaks, dtype=np.float64)
         zb = np.ascontiguousarray(z_breaks, dtype=np.float64)
         self._h = L.nfo_create(rt_order, p_order, ng, len(xb), _dp(xb), len(yb), _dp(yb), len(zb), _dp(zb))
+        if not self._h:
+            raise ValueError("oracle: x_breaks needs at least two entries and ng >= 1")
         self._L = L
         for key in ("dim", "nx", "ny", "nz", "ne", "ng", "k", "m", "nf", "ni", "nloc", "nJloc", "n_phi", "n_J"):
             setattr(self, key, L.nfo_info(self._h, key.encode()))

@@ -71,3 +71,19 @@ def synthetic_inputs(nx, ny, nz, ng, seed=0, dirichlet=(1, 2, 3, 4, 5, 6), nonun
 def rel_l2(a, b):
     a = np.asarray(a).ravel(); b = np.asarray(b).ravel()
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def degenerate_inputs(nx, ny, nz, ng=2, seed=3):
+    """meshes with a single cell along some axis: every axis that exists keeps its breaks (an axis with one cell has two);
+    the dimension follows the reference's rule dim = 3 if nz > 1 else 2 if ny > 1 else 1 (src/FEM.cpp:23-60)"""
+    rng = np.random.default_rng(seed)
+    brk = lambda n: np.concatenate([[0.0], np.cumsum(rng.uniform(0.5, 2.5, n))])
+    xb = brk(nx); yb = brk(ny) if (ny > 1 or nz > 1) else np.array([0.0]); zb = brk(nz) if nz > 1 else np.array([0.0])
+    dim = 3 if nz > 1 else (2 if ny > 1 else 1)
+    shp = (nz, ny, nx)[3 - dim:]
+    D = rng.uniform(0.2, 2.0, (ng,) + shp); SigR = rng.uniform(0.01, 0.2, (ng,) + shp); NSF = rng.uniform(0.0, 0.15, (ng,) + shp)
+    Chi = np.zeros((ng,) + shp); Chi[0] = 0.8; Chi[1] = 0.2
+    SigS = np.zeros((ng, ng) + shp); SigS[1, 0] = 0.02
+    attrs = {1: (1, 2), 2: (1, 2, 3, 4), 3: (1, 2, 3, 4, 5, 6)}[dim]
+    return dict(x_breaks=xb, y_breaks=yb, z_breaks=zb, D=D, SigR=SigR, NSF=NSF, Chi=Chi, SigS=SigS, bc_attr=np.array(attrs),
+                bc_type=np.zeros(len(attrs), dtype=int), ng=ng, coarse_factors=np.array([1, 1, 1]), kref=1.0)

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import make_hip, make_oracle, rel_l2, synthetic_inputs
+from helpers import degenerate_inputs, make_hip, make_oracle, rel_l2, synthetic_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -93,4 +93,21 @@ def test_long_x_lines(nx, rt):
     o.set_tol(1e-5, 1e-10, 1e-5, 10, 4000)
     xo, _, io = o.solve_group(0, b); xs, is_, _ = s.solve_group(0, b, 1e-10, 4000)
     assert rel_l2(xs, xo) < 1e-7 and abs(is_ - io) <= max(3, 0.03 * io)
+    s.close()
+
+
+@pytest.mark.parametrize("rt", [0, 2])
+@pytest.mark.parametrize("shape", [(4, 1, 3), (1, 5, 1), (1, 1, 7), (1, 1, 1), (1, 4, 6), (2, 1, 2), (1, 1, 2), (1, 2, 1), (5, 1, 1)])
+def test_single_cell_axes(shape, rt):
+    """one cell along x and / or y and / or z (lines of one cell, one line per pass, a 3D mesh with ny = 1 ...)"""
+    inp = degenerate_inputs(*shape)
+    o, s = make_oracle(inp, rt, rt), make_hip(inp, rt, rt)
+    assert (s.dim, s.nx, s.ny, s.nz) == (o.dim, o.nx, o.ny, o.nz)
+    x = np.random.default_rng(0).standard_normal(o.n_phi)
+    assert rel_l2(s.schur_apply(1, x), o.schur_apply(1, x)) < 1e-13
+    tol = (1e-10, 1e-10, 1e-10, 200, 500)
+    o.set_tol(*tol); s.set_tol(*tol)
+    ko = o.SolveKeff(); ks, n = s.solve_keff()
+    assert n == o.info("last_outer") and abs(ks - ko) / ko < 1e-11
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-10
     s.close()
