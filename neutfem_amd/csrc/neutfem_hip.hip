@@ -105,7 +105,7 @@ struct nf_team {
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (see k_schur_x)
-    int opt_fuse = 1;
+    int opt_fuse = 1, opt_xcd = 0;
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
 
@@ -716,6 +716,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
+    sa.xcd = T->opt_xcd;
     const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
 #define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
@@ -1550,6 +1551,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
+    else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
 }

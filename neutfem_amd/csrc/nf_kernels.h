@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const doub
 // touch no y.  mode 2 = final solve with the separator values u_lo/u_hi folded into the boundary data,
 // accumulate y on the chain cells and on the edge cells.
 struct SlabArgs {
-    int if_lo, if_hi, mode;
+    int if_lo, if_hi, mode, xcd;
     const double *alo, *ahi, *ulo, *uhi;      // per line
     double *clo, *chi;                        // per line (mode 1 outputs)
 };
@@ -554,10 +554,17 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
     const int T = TX * NSEG;
     double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T, *sred = sm + 4 * T + TX;
     const int tid = threadIdx.x, ixl = tid % TX, seg = tid / TX;
-    const int ix = blockIdx.x * TX + ixl;
+    // XCD-aware tile order (experiment, sa.xcd): hardware deals consecutive workgroups round-robin to the 8 XCDs; remap so that
+    // each XCD works on one contiguous range of tiles
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (sa.xcd) {
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
+    }
+    const int ix = bx * TX + ixl;
     const bool valid = ix < nx;
-    long base = (long)blockIdx.y * outer_stride + ix;
-    const long lineid = (long)blockIdx.y * nx + ix;
+    long base = (long)by * outer_stride + ix;
+    const long lineid = (long)by * nx + ix;
     // slab chain: cells [fs, fs+n) of the local line; x just outside the chain is real data (edge cells)
     double x_before = 0.0, x_after = 0.0, a_lo = 0.0, a_hi = 0.0, u_lo = 0.0, u_hi = 0.0;
     long edge_lo = 0, edge_hi = 0;
@@ -592,7 +599,7 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
                 x1[i] = v1; if (NB > 1) x2[i] = v2;
                 // cell coordinates for 1/c_e = D / factor_dir
                 int cx = ix, cy = 0, cz = 0;
-                if (DIR == 1) { cy = c; cz = blockIdx.y; } else { cy = blockIdx.y; cz = c; }
+                if (DIR == 1) { cy = c; cz = by; } else { cy = by; cz = c; }
                 icv[i] = ok ? ma.D[a] / geom_factor(G, DIR, cx, cy, cz) : 0.0;
             } else {
                 xLn = xv[i] + ma.eL[0] * ma.Gc[0] * v1 + (NB > 1 ? ma.eL[1] * ma.Gc[1] * v2 : 0.0);
@@ -682,7 +689,7 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
     }
     if (last && partials) {
         const double s = block_sum(dot, sred);
-        if (tid == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
+        if (tid == 0) partials[(long)by * gridDim.x + bx] = s;
     }
 }
 
