@@ -104,7 +104,6 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
-    CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (see k_schur_x)
     int opt_fuse = 1, opt_xcd = 0;
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
@@ -143,6 +142,7 @@ struct nf_solver {
     double *d_p0 = nullptr, *d_p1 = nullptr;            // Chebyshev history
     double *d_tf = nullptr, *d_rhs = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
     bool raw_valid = false, raw_is_diag = false;
+    CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
     bool cmfd_init = false; double cmfd_relax = 1.0;
     double *d_Dt[3] = {nullptr, nullptr, nullptr}, *d_Dh[3] = {nullptr, nullptr, nullptr}; long nfc[3] = {0, 0, 0};
@@ -664,7 +664,7 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const bool vec = (S->nx % 2 == 0);
     hipStream_t st = S->team->stream;
     const double *L = S->d_L[0] + g * N, *DR = S->d_DR[0] + g * N, *D0 = S->d_D0[0] + g * S->nlines[0];
-    const CgFuse fz = S->team->fuse;
+    const CgFuse fz = (S->if_lo || S->if_hi) ? CgFuse{ nullptr, nullptr, nullptr } : S->fuse;   // slabs fuse in their endpoint pass instead
     if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
     else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
 }
@@ -718,7 +718,8 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     SlabArgs sa; memset(&sa, 0, sizeof sa);
     sa.xcd = T->opt_xcd;
     const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
-#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa)
+    const CgFuse fz = zmode == 1 ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
+#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
         else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
     if (zmode != 0) {
@@ -853,8 +854,9 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     int launched = 0;
     int batch = T->cg_batch > 0 ? T->cg_batch : std::max(1, T->last_its[g] - 1), grow = 2;
     // fused variant (RT0-P0, undivided mesh): x_sol / p updates ride in the next x pass (k_schur_x, CgFuse)
-    const bool fused = T->opt_fuse && team_is_single(T) && T->slabs[0]->nloc == 1;
-    if (fused) T->fuse = CgFuse{ T->slabs[0]->d_p, T->slabs[0]->d_r, x[0] };
+    // (undivided mesh: in the x pass; slab teams: in the endpoint pass of the z lines, the first pass to read p)
+    const bool fused = T->opt_fuse && T->slabs[0]->nloc == 1;
+    for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
     int rc = NF_OK;
     while (launched < maxit && rc == NF_OK) {
         int nb = std::min(batch, maxit - launched);
@@ -885,9 +887,11 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         batch = T->cg_batch > 0 ? T->cg_batch : (launched < 8 ? 1 : grow);
         if (launched >= 8) grow = std::min(64, 2 * grow);
     }
-    T->fuse = CgFuse{ nullptr, nullptr, nullptr };
+    for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = CgFuse{ nullptr, nullptr, nullptr };
     NFCHK(rc);
-    if (fused) hipLaunchKernelGGL(k_cg_flush, dim3(gcnt[0]), dim3(256), 0, T->stream, x[0], (const double *)T->slabs[0]->d_p, T->slabs[0]->nphi, T->d_cg);
+    if (fused)
+        for (int i = 0; i < ns; ++i)
+            hipLaunchKernelGGL(k_cg_flush, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], (const double *)T->slabs[i]->d_p, T->slabs[i]->nphi, T->d_cg);
     if (launched == 0) {
         HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
         HIPCHK(hipStreamSynchronize(T->stream));

@@ -544,12 +544,16 @@ struct SlabArgs {
 template <int SEG, int DIR, bool SLAB, int NB>
 __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
-                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa)
+                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz)
 {
     static_assert(!(SLAB && NB > 0), "slabs are RT0-P0");
     extern __shared__ double sm[];
     if (cg && cg->done) return;
-    const double *__restrict__ x = ma.x[0];
+    const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
+    // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
+    // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread
+    const bool fuse = SLAB && sa.mode == 1 && fz.p != nullptr && cg->its > 0;
+    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
     double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
     double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T, *sred = sm + 4 * T + TX;
@@ -566,7 +570,7 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
     long base = (long)by * outer_stride + ix;
     const long lineid = (long)by * nx + ix;
     // slab chain: cells [fs, fs+n) of the local line; x just outside the chain is real data (edge cells)
-    double x_before = 0.0, x_after = 0.0, a_lo = 0.0, a_hi = 0.0, u_lo = 0.0, u_hi = 0.0;
+    double x_before = 0.0, x_after = 0.0, a_lo = 0.0, a_hi = 0.0, u_lo = 0.0, u_hi = 0.0, xe_lo = 0.0, xe_hi = 0.0;
     long edge_lo = 0, edge_hi = 0;
     if (SLAB) {
         const int fs = sa.if_lo ? 1 : 0;
@@ -575,8 +579,18 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
         edge_lo = base; edge_hi = base + (long)(nloc - 1) * sl;
         base += (long)fs * sl;
         if (valid) {
-            if (sa.if_lo) { a_lo = sa.alo[lineid]; x_before = x[edge_lo]; if (sa.mode == 2) { u_lo = sa.ulo[lineid]; x_before -= a_lo * u_lo; } }
-            if (sa.if_hi) { a_hi = sa.ahi[lineid]; x_after = x[edge_hi]; if (sa.mode == 2) { u_hi = sa.uhi[lineid]; x_after += a_hi * u_hi; } }
+            if (sa.if_lo) {
+                a_lo = sa.alo[lineid]; x_before = x[edge_lo];
+                if (fuse) { if (seg == 0) fz.xsol[edge_lo] += f_alpha * x_before; x_before = fz.r[edge_lo] + f_beta * x_before; }
+                xe_lo = x_before;
+                if (sa.mode == 2) { u_lo = sa.ulo[lineid]; x_before -= a_lo * u_lo; }
+            }
+            if (sa.if_hi) {
+                a_hi = sa.ahi[lineid]; x_after = x[edge_hi];
+                if (fuse) { if (seg == 0) fz.xsol[edge_hi] += f_alpha * x_after; x_after = fz.r[edge_hi] + f_beta * x_after; }
+                xe_hi = x_after;
+                if (sa.mode == 2) { u_hi = sa.uhi[lineid]; x_after += a_hi * u_hi; }
+            }
         }
     }
     const bool wr = !SLAB || sa.mode == 2;
@@ -589,6 +603,10 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
         xv[i] = ok ? x[a] : 0.0;
+        if (SLAB && fuse && ok) {
+            if (i < SEG) fz.xsol[a] += f_alpha * xv[i];             // owned cell; the overlap cell (i == SEG) belongs to the next segment
+            xv[i] = fz.r[a] + f_beta * xv[i];
+        }
         if (SLAB && valid && c == n) xv[i] = x_after;
         Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) Rv[i] = ok ? DR[a] : 0.0;
@@ -631,6 +649,11 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
     sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz;
     if (seg == 0) sZ0[ixl] = x_before - xL0;
     __syncthreads();
+    if (SLAB && fuse && valid) {                                 // every read of the old p in this block is behind the barrier
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) if (c0 + i < n) fz.p[base + (long)(c0 + i) * sl] = xv[i];
+        if (seg == 0) { if (sa.if_lo) fz.p[edge_lo] = xe_lo; if (sa.if_hi) fz.p[edge_hi] = xe_hi; }
+    }
     double z = sZ0[ixl];
     for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
     const double zin = z;
@@ -676,14 +699,14 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
     if (SLAB) {
         // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1
         if (valid && seg == 0 && sa.if_lo) {
-            if (sa.mode == 1) sa.clo[lineid] = -x[edge_lo] - a_lo * ulo;
+            if (sa.mode == 1) sa.clo[lineid] = -xe_lo - a_lo * ulo;
             else { const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv; }
         }
         if (valid && sa.if_hi && c0 <= n - 1 && n - 1 < c0 + SEG) {
             double ulast = 0.0;
 #pragma unroll
             for (int i = 0; i < SEG; ++i) if (c0 + i == n - 1) ulast = w[i];
-            if (sa.mode == 1) sa.chi[lineid] = x[edge_hi] - a_hi * ulast;
+            if (sa.mode == 1) sa.chi[lineid] = xe_hi - a_hi * ulast;
             else { const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv; }
         }
     }
