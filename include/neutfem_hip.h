@@ -155,7 +155,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  * "s_pair" (0/1: two columns per thread, 16-byte accesses) of the y/z line kernels; "cg_batch" CG iterations
  * launched between host checks of the device-side stop flag (0 = automatic); "cg_fuse" (default 1) folds the CG vector
  * updates x += alpha p, p = r + beta p into the next x pass on undivided RT0-P0 meshes (bit-identical iterates);
- * "xcd" (default 0) gives each XCD one contiguous range of y/z tiles (measured: no gain at 256^3). */
+ * "xcd" (default 0) gives each XCD one contiguous range of y/z tiles (measured: no gain at 256^3);
+ * "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD). */
 int nf_set_option(nf_handle h, const char *key, long value);
 
 /* raw device-memory helpers so callers without torch can drive the *_dev entry points */

@@ -104,7 +104,8 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
-    int opt_fuse = 1, opt_xcd = 0;
+    int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1;
+    OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
 
@@ -238,7 +239,7 @@ static int team_alloc(nf_team *T)
     long cap = 0;
     for (auto *S : T->slabs) cap = std::max(cap, slab_partial_need(S));
     T->slab_cap = cap; T->partial_stride = cap * (long)T->slabs.size();
-    NFCHK(dalloc(&T->d_partials, (size_t)T->partial_stride * 3));
+    NFCHK(dalloc(&T->d_partials, (size_t)T->partial_stride * 4));
     if (!T->d_cg) NFCHK(dalloc(&T->d_cg, 1));
     if (!T->d_out) NFCHK(dalloc(&T->d_out, 4));
     if (!T->d_red) NFCHK(dalloc(&T->d_red, 4));
@@ -253,7 +254,7 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
-    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red);
+    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_ost); dfree(T->d_hist);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
     if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
     if (T->ev_xchg) (void)hipEventDestroy(T->ev_xchg);
@@ -1232,6 +1233,58 @@ static int cmfd_step(nf_solver *S, double keff, int use_diag)
     return NF_OK;
 }
 
+// ---- diagonal path, outer loop on the device (undivided mesh, no CMFD) --------------------------------------------
+static int solve_keff_diag_device(nf_team *T, const nf_keff_opts *o, double keff0, const double *ca, const double *cbv, double sigma,
+                                  double *keff_out)
+{
+    nf_solver *S = T->slabs[0];
+    const int ng = S->ng; const long N = S->N, NP = S->nphi, NT = NP * ng;
+    hipStream_t st = T->stream;
+    if (!S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NT)); NFCHK(dalloc(&S->d_p1, (size_t)NT)); }
+    if (!T->d_ost) NFCHK(dalloc(&T->d_ost, 1));
+    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer)); T->hist_cap = o->max_outer; }
+    double *hk = T->d_hist, *hdk = hk + T->hist_cap, *hdp = hdk + T->hist_cap;
+    OuterState h; memset(&h, 0, sizeof h);
+    h.keff = keff0; h.tol_keff = o->tol_keff; h.tol_flux = o->tol_flux; h.max_outer = o->max_outer;
+    h.ca1 = ca[1];
+    for (int i = 2; i < 15; ++i) { h.a3[i] = (4. / sigma) * ca[i]; h.cb[i] = cbv[i]; }
+    HIPCHK(hipMemcpyAsync(T->d_ost, &h, sizeof h, hipMemcpyHostToDevice, st));
+    const int gN = grid_for(NP);
+    const long stride = T->partial_stride;
+    hipLaunchKernelGGL(k_fission, dim3(gN), dim3(256), 0, st, S->d_Mf, S->d_phi, ng, NP, S->d_tf, T->d_partials, (const double *)nullptr, 0L);
+    ScatterArgs sa; sa.ng = ng;
+    OuterState hs = h;
+    int queued = 0;
+    while (queued < o->max_outer) {
+        const int nb = std::min(queued == 0 ? 8 : 32, o->max_outer - queued);
+        for (int b = 0; b < nb; ++b) {
+            for (int g = 0; g < ng; ++g) {
+                for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[g * ng + gp] : nullptr;
+                hipLaunchKernelGGL(k_diag_group, dim3(gN), dim3(256), 0, st, sa, g, S->d_Chi + g * N, S->d_tf, S->d_raw, S->d_phi, S->d_Sinv + g * N,
+                                   S->d_Mf + (size_t)g * NP, S->d_raw + (size_t)g * NP, NP, T->d_ost, T->d_partials, stride);
+            }
+            hipLaunchKernelGGL(k_outer_logic, dim3(1), dim3(256), 0, st, T->d_partials, gN, gN, stride, T->d_ost, hk, hdk, hdp);
+            hipLaunchKernelGGL(k_normalize_fission, dim3(gN), dim3(256), 0, st, S->d_raw, S->d_phi, S->d_p0, S->d_p1, S->d_Mf, ng, NP, T->d_ost, S->d_tf, T->d_partials);
+        }
+        queued += nb;
+        HIPCHK(hipMemcpyAsync(&hs, T->d_ost, sizeof hs, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hs.done || hs.done_next) break;
+    }
+    HIPCHK(hipGetLastError());
+    const int n = hs.it;
+    T->hist_k.resize(n); T->hist_dk.resize(n); T->hist_dphi.resize(n); T->hist_cg.assign((size_t)n * ng, 0);
+    if (n > 0) {
+        HIPCHK(hipMemcpy(T->hist_k.data(), hk, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_dk.data(), hdk, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_dphi.data(), hdp, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    T->last_outer = n; T->last_cg_total = 0;
+    if (hs.done == 2) return fail(NF_ERR_NUMERIC, "power iteration diverged (outer %d: k=%g dphi=%g)", n - 1, T->hist_k[n - 1], T->hist_dphi[n - 1]);
+    *keff_out = hs.keff;
+    return NF_OK;
+}
+
 // ---- SolveKeff (src/NeutFEM.cpp:1627-1815) -----------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, int *n_outer)
 {
@@ -1269,6 +1322,16 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     T->hist_k.clear(); T->hist_dk.clear(); T->hist_dphi.clear(); T->hist_cg.clear();
     T->last_outer = 0; T->last_cg_total = 0;
     T->profile = o->profile != 0;
+    if (use_diag && single && !use_cmfd && !T->rccl_reduce && T->opt_outer_dev && o->max_outer > 0) {
+        NFCHK(solve_keff_diag_device(T, o, keff, ca, cbv, sigma, &keff));
+        HIPCHK(hipStreamSynchronize(T->stream));
+        T->profile = false;
+        S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = true;
+        T->has_valid_keff = 1; T->last_keff = keff;
+        if (keff_out) *keff_out = keff;
+        if (n_outer) *n_outer = T->last_outer;
+        return NF_OK;
+    }
     ScatterArgs sa; sa.ng = ng;
     double hout[4];
     std::vector<int> gN(ns), gT(ns);
@@ -1556,6 +1619,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
+    else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
 }

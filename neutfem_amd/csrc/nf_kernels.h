@@ -852,6 +852,121 @@ __global__ __launch_bounds__(256) void k_normalize_cheb(const double *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diagonal-Schur power iteration with the whole outer loop on the device (undivided RT0-P0 mesh, no CMFD): an outer
+// iteration is ng pointwise group solves, one scalar kernel and one normalise kernel, all a few microseconds on the
+// benchmark meshes, so a host round trip per outer would dominate.  The scalar logic of src/NeutFEM.cpp:1766-1802 and of
+// ChebyshevAccel (src/solvers.cpp:720-756) lives in k_outer_logic; the host launches batches of outers and reads the
+// state once per batch.  Kernels of outers queued behind the last one exit on `done`.
+struct OuterState {
+    double keff, norm, a, b;
+    double tol_keff, tol_flux;
+    double ca1, a3[16], cb[16];     // Chebyshev coefficients: a_1, (4/sigma) a_n and b_n for n >= 2 (host-computed, same bits)
+    int mode, do_norm, it, cheb_it, swap, swap_next, max_outer;
+    int done;                       // 0 running, 1 finished (converged or max_outer), 2 diverged
+    int done_next;                  // the current outer is the last one: its normalise kernel still runs (:1780-1802)
+};
+// group g: rhs = chi_g tf / k + scatter (Gauss-Seidel), raw_g = S_inv rhs (:607-613), and this group's share of
+// prod_new = sum M_f raw, |raw|^2, |raw - phi_old|^2 (:1766-1779) accumulated block-wise over the groups (g = 0 stores)
+__global__ __launch_bounds__(256) void k_diag_group(ScatterArgs sa, int g, const double *__restrict__ chi, const double *__restrict__ tf,
+                                                    const double *__restrict__ raw_all, const double *__restrict__ phi_old,
+                                                    const double *__restrict__ sinv, const double *__restrict__ Mf, double *__restrict__ out,
+                                                    long n, const OuterState *__restrict__ st, double *__restrict__ partials, long stride)
+{
+    __shared__ double sred[4];
+    if (st->done || st->done_next) return;
+    const double inv_k = 1.0 / st->keff;
+    double sp = 0.0, sn = 0.0, sd = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        double v = inv_k * (chi[i] * tf[i]);
+        for (int gp = 0; gp < sa.ng; ++gp) {
+            if (gp == g || !sa.M[gp]) continue;
+            const double *ph = gp < g ? raw_all : phi_old;
+            v += sa.M[gp][i] * ph[gp * n + i];
+        }
+        const double r = sinv[i] * v, d = r - phi_old[g * n + i];
+        out[i] = r;
+        sp += Mf[i] * r; sn += r * r; sd += d * d;
+    }
+    sp = block_sum(sp, sred); sn = block_sum(sn, sred); sd = block_sum(sd, sred);
+    if (threadIdx.x == 0) {
+        double *p1 = partials + stride + blockIdx.x, *p2 = partials + 2 * stride + blockIdx.x, *p3 = partials + 3 * stride + blockIdx.x;
+        if (g == 0) { *p1 = sp; *p2 = sn; *p3 = sd; } else { *p1 += sp; *p2 += sn; *p3 += sd; }
+    }
+}
+// one block: sums of the four partial rows (row 0: prod_old from k_fission / k_normalize_fission), then the scalar logic
+__global__ __launch_bounds__(256) void k_outer_logic(const double *__restrict__ partials, int cnt0, int cnt, long stride,
+                                                     OuterState *__restrict__ st, double *__restrict__ hist_k,
+                                                     double *__restrict__ hist_dk, double *__restrict__ hist_dphi)
+{
+    __shared__ double sred[4];
+    if (st->done) return;
+    if (st->done_next) { if (threadIdx.x == 0) st->done = 1; return; }
+    double tot[4];
+    for (int q = 0; q < 4; ++q) {
+        double s = 0.0;
+        const int c = q == 0 ? cnt0 : cnt;
+        for (int i = threadIdx.x; i < c; i += 256) s += partials[q * stride + i];
+        tot[q] = block_sum(s, sred);
+    }
+    if (threadIdx.x != 0) return;
+    const double prod_old = tot[0], prod_new = tot[1], nsq = tot[2], dsq = tot[3];
+    const int it = st->it;
+    double keff = st->keff;
+    const double keff_new = keff * (prod_new / prod_old);
+    const double dk = fabs(keff_new - keff);
+    if (it >= 1) keff = keff_new;                               // :1774
+    const double dphi = sqrt(dsq / nsq), norm = sqrt(nsq);
+    st->keff = keff;
+    hist_k[it] = keff; hist_dk[it] = dk; hist_dphi[it] = dphi;
+    if (!isfinite(keff_new) || !isfinite(dphi)) { st->it = it + 1; st->done = 2; return; }
+    int mode = 0; double a = 0.0, b = 0.0;
+    int cheb_it = st->cheb_it;
+    if (it >= 2) {                                              // src/solvers.cpp:720-756
+        if (cheb_it == 15) cheb_it = 0;
+        if (cheb_it == 0) mode = 1;
+        else if (cheb_it == 1) { mode = 2; a = st->ca1; }
+        else { mode = 3; a = st->a3[cheb_it]; b = st->cb[cheb_it]; }
+        ++cheb_it;
+    }
+    st->cheb_it = cheb_it;
+    st->swap = st->swap_next;                                   // orientation of (p0, p1) for this outer's normalise kernel
+    st->swap_next = st->swap ^ (mode == 3 ? 1 : 0);
+    st->mode = mode; st->a = a; st->b = b; st->norm = norm; st->do_norm = norm > 1e-14 ? 1 : 0;
+    st->it = it + 1;
+    if ((dk < st->tol_keff && dphi < st->tol_flux) || it + 1 >= st->max_outer) st->done_next = 1;   // :1799-1802
+}
+// phi_g = Chebyshev(raw_g / norm) for every group of a cell, and the next outer's total_fiss + prod_old partials (:1700-1707)
+__global__ __launch_bounds__(256) void k_normalize_fission(const double *__restrict__ raw, double *__restrict__ cur,
+                                                           double *__restrict__ p0, double *__restrict__ p1,
+                                                           const double *__restrict__ Mf, int ng, long n,
+                                                           const OuterState *__restrict__ st, double *__restrict__ tf,
+                                                           double *__restrict__ partials)
+{
+    __shared__ double sred[4];
+    if (st->done) return;
+    const double norm = st->norm, ca = st->a, cb = st->b;
+    const int do_norm = st->do_norm, mode = st->mode;
+    double *pa = st->swap ? p1 : p0, *pb = st->swap ? p0 : p1;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        double t = 0.0;
+        for (int g = 0; g < ng; ++g) {
+            const long j = g * n + i;
+            double v = raw[j];
+            if (do_norm) v /= norm;
+            if (mode == 1) pa[j] = v;
+            else if (mode == 2) { const double a = pa[j]; v = a + ca * (v - a); pb[j] = v; }
+            else if (mode == 3) { const double a = pa[j], b = pb[j]; v = b + ca * (v - b) + cb * (b - a); pa[j] = v; }
+            cur[j] = v;
+            t += Mf[j] * v;
+        }
+        tf[i] = t; s += t;
+    }
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
 // adjoint helpers: sum over groups, weighted dot product, scaling
 __global__ void k_sum_groups(const double *__restrict__ a, double *__restrict__ out, long n, int ng)
 {
