@@ -853,7 +853,9 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
     CgScalars sc; memset(&sc, 0, sizeof sc);
     int launched = 0;
-    int batch = T->cg_batch > 0 ? T->cg_batch : std::max(1, T->last_its[g] - 1), grow = 2;
+    // first batch: what the previous solve of this group needed, plus two (an iteration launched past convergence costs five
+    // early-exit kernels, ~10 us; a second host check costs a D2H copy and a stream drain, ~50 us)
+    int batch = T->cg_batch > 0 ? T->cg_batch : (T->last_its[g] > 0 ? T->last_its[g] + 2 : 1), grow = 2;
     // fused variant (RT0-P0, undivided mesh): x_sol / p updates ride in the next x pass (k_schur_x, CgFuse)
     // (undivided mesh: in the x pass; slab teams: in the endpoint pass of the z lines, the first pass to read p)
     const bool fused = T->opt_fuse && T->slabs[0]->nloc == 1;
