@@ -228,6 +228,19 @@ static ModeArgs mode_args(const nf_solver *S, int g, int d, int mode, const doub
     ma.eL[1] = -7.0 / 8.0; ma.eR[1] = 7.0 / 8.0; ma.Gc[1] = -4.0 / 5.0; ma.iM[1] = 105.0 / 16.0;
     return ma;
 }
+// every transverse mode of direction d relative to mode 0 (ModeTab): T_a and moment offsets
+static ModeTab mode_tab(const nf_solver *S, int d)
+{
+    ModeTab mt; memset(&mt, 0, sizeof mt);
+    mt.n = n_modes(S);
+    for (int m = 0; m < mt.n; ++m)
+        for (int i = 0; i <= S->nb; ++i) {
+            double Ta = 1.0;
+            const int p = moment_index(S, d, m, i, &Ta), p0 = moment_index(S, d, 0, i, nullptr);
+            mt.Ta[m] = Ta; mt.doff[m][i] = (long)(p - p0) * S->N;
+        }
+    return mt;
+}
 
 // ---- team management ---------------------------------------------------------------------------
 static long slab_partial_need(const nf_solver *S)
@@ -666,8 +679,10 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     hipStream_t st = S->team->stream;
     const double *L = S->d_L[0] + g * N, *DR = S->d_DR[0] + g * N, *D0 = S->d_D0[0] + g * S->nlines[0];
     const CgFuse fz = (S->if_lo || S->if_hi) ? CgFuse{ nullptr, nullptr, nullptr } : S->fuse;   // slabs fuse in their endpoint pass instead
-    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
-    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), dim3(grid), dim3(256), 0, st, ma, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
+    const ModeTab mt = mode_tab(S, 0);
+    const dim3 gr(grid, (unsigned)mt.n);                          // all transverse modes in one launch
+    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
+    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
 }
 template <int NB>
 static int launch_x_nb(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts)
@@ -678,7 +693,7 @@ static int launch_x_nb(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const int LPL = 1 << lpl_log2, LPW = 64 / LPL;
     const int nch = (S->nx + LPL * K - 1) / (LPL * K);
     const unsigned grid = (unsigned)((S->nlines[0] + 4 * LPW - 1) / (4 * LPW));
-    if (nparts) *nparts = (int)grid;
+    if (nparts) *nparts = (int)grid * n_modes(S);
     if (nch <= 1) launch_x_t<1, NB>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
     else if (nch <= 2) launch_x_t<2, NB>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
     else if (nch <= 4) launch_x_t<4, NB>(S, g, ma, G, lpl_log2, 1, last, partials, cg, grid);
@@ -712,15 +727,16 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     while (TX > 8 && TX * NSEG > 1024) TX >>= 1;
     if (TX * NSEG > 1024) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than 1024 threads per block", n);
     while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;                   // narrow meshes
-    dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter), block((unsigned)(TX * NSEG));
-    if (nparts) *nparts = (int)(grid.x * grid.y);
+    const ModeTab mt = zmode != 0 ? ModeTab{ 1, { 1.0 }, { { 0 } } } : mode_tab(S, d);
+    dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter, (unsigned)mt.n), block((unsigned)(TX * NSEG));
+    if (nparts) *nparts = (int)(grid.x * grid.y * grid.z);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
     sa.xcd = T->opt_xcd;
     const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
     const CgFuse fz = zmode == 1 ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
-#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz)
+#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
         else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
     if (zmode != 0) {
@@ -788,9 +804,9 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
             nf_solver *S = T->slabs[i];
             const Geom G = make_geom(S);
             int total = 0;
-            for (int mode = 0; mode < n_modes(S); ++mode) {
-                double *part = (want_dot && last) ? T->d_partials + i * T->slab_cap + total : nullptr;
-                const ModeArgs ma = mode_args(S, g, d, mode, xs[i], ys[i]);
+            {
+                double *part = (want_dot && last) ? T->d_partials + i * T->slab_cap : nullptr;
+                const ModeArgs ma = mode_args(S, g, d, 0, xs[i], ys[i]);     // mode 0; the kernels derive the others (ModeTab)
                 int np = 0;
                 if (d == 0) NFCHK(launch_x(S, g, ma, G, last, part, cg, &np));
                 else if (d == 2 && (S->if_lo || S->if_hi)) {

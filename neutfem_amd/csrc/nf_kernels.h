@@ -207,6 +207,18 @@ struct ModeArgs {
     int dir;
 };
 
+// All transverse modes of one direction in ONE launch (they touch disjoint moments): the kernels get the ModeArgs of mode 0
+// plus, per mode, T_a and the offset of its moments relative to mode 0's; the mode is the last grid dimension.
+struct ModeTab { int n; double Ta[9]; long doff[9][3]; };
+__device__ __forceinline__ ModeArgs select_mode(ModeArgs ma, const ModeTab &mt, int m, int nbp1)
+{
+    if (mt.n > 1) {
+        ma.Ta = mt.Ta[m];
+        for (int i = 0; i < nbp1; ++i) { const long o = mt.doff[m][i]; ma.x[i] += o; ma.y[i] += o; ma.Cd[i] += o; }
+    }
+    return ma;
+}
+
 // AssembleA + ApplyDirichletToA + SparseLU (src/NeutFEM.cpp:1036-1076,1328-1456; src/solvers.cpp:163)
 // for one direction: one thread per grid line assembles the tridiagonal T of that line on the fly
 // and stores its LDL^T factor cell-aligned: L[e] couples the lower to the upper face of cell e,
@@ -385,7 +397,7 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
 // The last iteration's x_sol update is applied by k_cg_flush (CgScalars::pend).
 struct CgFuse { double *p; const double *r; double *xsol; };
 template <int K, int NCH, bool VEC, int NB>
-__global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+__global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                                                  const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
                                                  int first, int last, double *__restrict__ partials,
                                                  const CgScalars *__restrict__ cg, CgFuse fz)
@@ -393,6 +405,7 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const doub
     static_assert(K == 2, "two cells per lane and chunk");
     __shared__ double sred[4];
     if (cg && cg->done) return;
+    const ModeArgs ma = select_mode(ma0, mt, blockIdx.y, NB + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int LPL = 1 << lpl_log2, LPW = 64 >> lpl_log2;
     const int li = lane & (LPL - 1), sub = lane >> lpl_log2;
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma, Geom G, const doub
     }
     if (last && partials) {
         const double s = block_sum(dot, sred);
-        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+        if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -542,13 +555,14 @@ struct SlabArgs {
     double *clo, *chi;                        // per line (mode 1 outputs)
 };
 template <int SEG, int DIR, bool SLAB, int NB>
-__global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+__global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                           int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz)
 {
     static_assert(!(SLAB && NB > 0), "slabs are RT0-P0");
     extern __shared__ double sm[];
     if (cg && cg->done) return;
+    const ModeArgs ma = select_mode(ma0, mt, blockIdx.z, NB + 1);
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
     // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread
@@ -712,7 +726,7 @@ __global__ void k_schur_s(ModeArgs ma, Geom G, const double *__restrict__ L, con
     }
     if (last && partials) {
         const double s = block_sum(dot, sred);
-        if (tid == 0) partials[(long)by * gridDim.x + bx] = s;
+        if (tid == 0) partials[((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx] = s;
     }
 }
 
