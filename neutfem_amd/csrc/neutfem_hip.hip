@@ -874,7 +874,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     int batch = T->cg_batch > 0 ? T->cg_batch : (T->last_its[g] > 0 ? T->last_its[g] + 2 : 1), grow = 2;
     // fused variant (RT0-P0, undivided mesh): x_sol / p updates ride in the next x pass (k_schur_x, CgFuse)
     // (undivided mesh: in the x pass; slab teams: in the endpoint pass of the z lines, the first pass to read p)
-    const bool fused = T->opt_fuse && T->slabs[0]->nloc == 1;
+    const bool fused = T->opt_fuse != 0;                          // slab teams are RT0-P0; an undivided mesh fuses at any order
     for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
     int rc = NF_OK;
     while (launched < maxit && rc == NF_OK) {

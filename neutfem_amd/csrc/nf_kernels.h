@@ -391,7 +391,8 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
     if (vec) { double2 v = make_double2(0, 0); if (ok) v = *reinterpret_cast<const double2 *>(p + i); a = v.x; b = v.y; }
     else { a = ok ? p[i] : 0.0; b = ok2 ? p[i + 1] : 0.0; }
 }
-// Fused CG (RT0-P0, undivided mesh): the vector updates that follow FIN_RR -- x_sol += alpha p and p = r + beta p
+// Fused CG (undivided mesh, any order: the x pass with all its transverse modes touches every moment exactly once): the
+// vector updates that follow FIN_RR -- x_sol += alpha p and p = r + beta p
 // (src/solvers.cpp:609,630) -- are deferred to the next iteration's x pass, which reads p anyway: p is read once instead
 // of three times per iteration and one launch disappears.  Same operands, same expressions: bit-identical iterates.
 // The last iteration's x_sol update is applied by k_cg_flush (CgScalars::pend).
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
     const long base = lv ? line * nx : 0;
     const int iy = lv ? (int)(line % ny) : 0, iz = lv ? (int)(line / ny) : 0;
     double xm[NB + 1][NCH][K], yo[NB + 1][NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], xL[NCH][K], xR[NCH][K], ic[NCH][K];
-    const bool fuse = NB == 0 && fz.p != nullptr && cg->its > 0;
+    const bool fuse = fz.p != nullptr && cg->its > 0;
     const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -427,18 +428,22 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
             ld2(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
             ld2(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
         }
-        if (NB == 0 && fuse) {
-            double r0, r1, s0, s1;
-            ld2(fz.r, base + c0, ok, VEC, r0, r1, ok2);
-            ld2(fz.xsol, base + c0, ok, VEC, s0, s1, ok2);
-            s0 += f_alpha * xm[0][ch][0]; s1 += f_alpha * xm[0][ch][1];
-            xm[0][ch][0] = r0 + f_beta * xm[0][ch][0]; xm[0][ch][1] = r1 + f_beta * xm[0][ch][1];
-            if (VEC) {
-                if (ok) { *reinterpret_cast<double2 *>(fz.xsol + base + c0) = make_double2(s0, s1);
-                          *reinterpret_cast<double2 *>(fz.p + base + c0) = make_double2(xm[0][ch][0], xm[0][ch][1]); }
-            } else {
-                if (ok) { fz.xsol[base + c0] = s0; fz.p[base + c0] = xm[0][ch][0]; }
-                if (ok2) { fz.xsol[base + c0 + 1] = s1; fz.p[base + c0 + 1] = xm[0][ch][1]; }
+        if (fuse) {
+#pragma unroll
+            for (int q = 0; q <= NB; ++q) {                      // ma.x[q] points into p: the same offset addresses r and x_sol
+                const long mo = (ma.x[q] - fz.p) + base + c0;
+                double r0, r1, s0, s1;
+                ld2(fz.r, mo, ok, VEC, r0, r1, ok2);
+                ld2(fz.xsol, mo, ok, VEC, s0, s1, ok2);
+                s0 += f_alpha * xm[q][ch][0]; s1 += f_alpha * xm[q][ch][1];
+                xm[q][ch][0] = r0 + f_beta * xm[q][ch][0]; xm[q][ch][1] = r1 + f_beta * xm[q][ch][1];
+                if (VEC) {
+                    if (ok) { *reinterpret_cast<double2 *>(fz.xsol + mo) = make_double2(s0, s1);
+                              *reinterpret_cast<double2 *>(fz.p + mo) = make_double2(xm[q][ch][0], xm[q][ch][1]); }
+                } else {
+                    if (ok) { fz.xsol[mo] = s0; fz.p[mo] = xm[q][ch][0]; }
+                    if (ok2) { fz.xsol[mo + 1] = s1; fz.p[mo + 1] = xm[q][ch][1]; }
+                }
             }
         }
 #pragma unroll
