@@ -228,10 +228,10 @@ def main():
                                alg_bytes=algorithmic_bytes(dim, Nl, nJd[d]) + (fused_bytes if d == 0 else 0.0)))
     dom = max(passes, key=lambda p: p["avg_ms"])
     # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    # command, gfx950 x2 read correction; profiles/r01_c_pmc_traffic_256cube.json, made by profiles/collect.sh).  Per-cell figure x cells of this run.
+    # command, gfx950 x2 read correction; profiles/r01_d_pmc_traffic_256cube.json, made by profiles/collect.sh).  Per-cell figure x cells of this run.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_256cube.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_256cube.json")) as f:
             pmc = json.load(f)["kernels"]
         key = {"schur_x": "k_schur_x<2, 2, true, 0>", "schur_y": "k_schur_s<8, 1, false, 0>", "schur_z": "k_schur_s<8, 2, false, 0>"}[dom["name"]]
         if a.n == 256 and a.case == "iaea3d" and slabs_total == 1:
