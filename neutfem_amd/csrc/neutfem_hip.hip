@@ -39,7 +39,7 @@ static int fail(int code, const char *fmt, ...)
 static const int RED_GRID = 1024;          // fixed grid of the streaming/reduction kernels
 static const int MAX_LOCAL_SLABS = 16;
 
-struct ProfSlot { long count = 0; double ms = 0.0; };
+struct ProfSlot { long count = 0; double ms = 0.0; double max_ms = 0.0; long skipped = 0; };
 
 // ---- RCCL, resolved lazily with dlopen so that single-GPU use never loads it -------------------
 typedef struct ncclComm *ncclComm_t;
@@ -547,14 +547,22 @@ static void prof_begin(nf_team *T, int slot, hipEvent_t *a, hipEvent_t *b)
     (void)hipEventRecord(*a, T->stream);
     T->ev_pending.push_back({*a, *b, slot});
 }
+// Launches queued behind a converged CG solve exit at once (CgScalars::done); they are no work and must not dilute the
+// average duration of a pass: samples shorter than a quarter of the slot's longest one are counted apart (`skipped`).
 static void prof_collect(nf_team *T)
 {
+    std::vector<std::pair<int, float>> got;
     for (auto &e : T->ev_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            auto &sl = T->prof[SLOT_NAMES[e.slot]]; sl.count += 1; sl.ms += ms;
+            got.push_back({e.slot, ms});
+            auto &sl = T->prof[SLOT_NAMES[e.slot]]; if (ms > sl.max_ms) sl.max_ms = ms;
         }
         T->ev_free.push_back({e.a, e.b});
+    }
+    for (auto &g : got) {
+        auto &sl = T->prof[SLOT_NAMES[g.first]];
+        if (g.second < 0.25 * sl.max_ms) sl.skipped += 1; else { sl.count += 1; sl.ms += g.second; }
     }
     T->ev_pending.clear();
 }
