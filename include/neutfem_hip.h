@@ -59,6 +59,8 @@ int nf_create_slab(int rt_order, int p_order, int ng,
 int nf_link_slabs(nf_handle *handles, int n);
 int nf_comm_unique_id(void *id128_host);
 int nf_comm_init(nf_handle h, const void *id128_host, int nranks, int rank);
+/* diagnostic: grouped ncclSend/ncclRecv to the own rank on the comm stream + all-reduce(max) through the loaded RCCL */
+int nf_comm_selftest(nf_handle h);
 /* Schur apply on every local slab: x_dev[i] / y_dev[i] = device vectors of local slab i */
 int nf_team_schur_apply(nf_handle h, int g, const double *const *x_dev, double *const *y_dev);
 

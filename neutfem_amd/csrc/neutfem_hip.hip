@@ -437,6 +437,47 @@ int nf_comm_init(nf_handle S, const void *id128, int nranks, int rank)
     return NF_OK;
 }
 
+// Diagnostic: the point-to-point calls of the plane exchange against the loaded RCCL, on this rank alone -- a grouped
+// ncclSend / ncclRecv pair to and from the own rank on the comm stream, ordered against the main stream with the same
+// events the Schur apply uses, followed by an all-reduce(max).  Verifies the dlsym'd signatures and the stream / event
+// choreography with the real library where only one GPU is available.
+int nf_comm_selftest(nf_handle S)
+{
+    if (!S) return fail(NF_ERR_ARG, "null handle");
+    nf_team *T = S->team;
+    if (!T->comm) return fail(NF_ERR_STATE, "nf_comm_selftest: no communicator (call nf_comm_init first)");
+    HIPCHK(hipSetDevice(T->device));
+    const size_t n = 1 << 16;
+    double *a = nullptr, *b = nullptr;
+    NFCHK(dalloc(&a, n)); if (dalloc(&b, n) != NF_OK) { dfree(a); return NF_ERR_HIP; }
+    hipStream_t cs = T->comm_stream ? T->comm_stream : T->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreateWithFlags(&e0, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+    int rc = NF_OK;
+    hipLaunchKernelGGL(k_fill_pattern, dim3(64), dim3(256), 0, T->stream, a, (long)n);
+    (void)hipMemsetAsync(b, 0, n * sizeof(double), T->stream);
+    (void)hipEventRecord(e0, T->stream); (void)hipStreamWaitEvent(cs, e0, 0);
+    if (g_rccl.GroupStart() != 0 || g_rccl.Send(a, n, NCCL_DOUBLE, T->rank, T->comm, cs) != 0 ||
+        g_rccl.Recv(b, n, NCCL_DOUBLE, T->rank, T->comm, cs) != 0 || g_rccl.GroupEnd() != 0) rc = fail(NF_ERR_HIP, "nf_comm_selftest: grouped ncclSend/ncclRecv failed");
+    (void)hipEventRecord(e1, cs); (void)hipStreamWaitEvent(T->stream, e1, 0);
+    double w = 3.25;
+    if (rc == NF_OK) {
+        (void)hipMemcpyAsync(T->d_red, &w, sizeof w, hipMemcpyHostToDevice, T->stream);
+        if (g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream) != 0) rc = fail(NF_ERR_HIP, "nf_comm_selftest: ncclAllReduce(max) failed");
+        (void)hipMemcpyAsync(&w, T->d_red, sizeof w, hipMemcpyDeviceToHost, T->stream);
+    }
+    std::vector<double> ha(n), hb(n);
+    if (hipStreamSynchronize(T->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "nf_comm_selftest: stream failed");
+    if (rc == NF_OK) {
+        (void)hipMemcpy(ha.data(), a, n * sizeof(double), hipMemcpyDeviceToHost); (void)hipMemcpy(hb.data(), b, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (memcmp(ha.data(), hb.data(), n * sizeof(double)) != 0) rc = fail(NF_ERR_NUMERIC, "nf_comm_selftest: received plane differs from the sent one");
+        else if (T->nproc == 1 && w != 3.25) rc = fail(NF_ERR_NUMERIC, "nf_comm_selftest: all-reduce(max) returned %g", w);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dfree(a); dfree(b);
+    return rc;
+}
+
 long nf_info(nf_handle S, const char *key)
 {
     if (!S || !key) return -1;

@@ -1,7 +1,8 @@
 """GPU tests of the z-slab decomposition in loopback (all slabs of the team on the one GPU of the test box):
 the partition-method z-line solve, the team CG and the team power iteration against the undivided HIP solve and
-the oracle.  The RCCL transport itself (ncclSend/Recv/AllReduce between processes) cannot run here -- RCCL refuses
-two ranks on one device -- and is exercised by the driver's multi-GPU bench."""
+the oracle.  RCCL refuses two ranks on one device: here the real library is driven with one rank (all-reduces in the solve,
+ncclSend/ncclRecv to the own rank in nf_comm_selftest); several real processes run in tests/test_gpu_multiproc.py over a
+host-staged stand-in transport; RCCL between GPUs is exercised by the driver's multi-GPU bench."""
 import numpy as np
 import pytest
 
@@ -99,12 +100,14 @@ def test_team_driver_tolerances_iaea3d_like():
 
 def test_rccl_allreduce_path_single_rank(monkeypatch):
     """NEUTFEM_FORCE_RCCL=1 builds a real 1-rank RCCL communicator and routes every scalar reduction of the solve
-    through ncclAllReduce on the solver's stream (what one cannot test here is ncclSend/ncclRecv between ranks)."""
+    through ncclAllReduce on the solver's stream; nf_comm_selftest drives ncclSend/ncclRecv of the same library (to the own
+    rank -- between ranks the call pattern is covered by tests/test_gpu_multiproc.py with the stand-in transport)."""
     from neutfem_amd.capi import HipTeam
     monkeypatch.setenv("NEUTFEM_FORCE_RCCL", "1")
     inp = synthetic_inputs(12, 8, 80, 2, seed=3)
     s, t = make_hip(inp), make_team(inp, [(0, 40), (40, 80)])
     t.comm_init(HipTeam.unique_id(), 1, 0)
+    t.comm_selftest()            # real RCCL: grouped ncclSend/ncclRecv (to self) on the comm stream with the apply's event pattern, all-reduce(max)
     tol = (1e-9, 1e-9, 1e-9, 500, 2000)
     s.set_tol(*tol); t.set_tol(*tol)
     ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
