@@ -1,0 +1,73 @@
+"""Randomised call sequences through the reference's Python surface (pybind11 module on the GPU) against the oracle with the
+same method names: state that survives between calls -- warm flux and k, D-hat of the CMFD, the diagonal cache, the effect
+of BuildMatrices after cross sections were edited in place, reset_flux, changed tolerances -- must evolve identically."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import degenerate_inputs, make_oracle, rel_l2, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(inp, rt, p):
+    import neutfem_amd
+    neutfem_amd.install_compat()
+    import neutfem._neutfem_eigen as ns
+    m = ns.NeutFEM(rt, p, int(inp["ng"]), inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    m.set_verbosity(ns.VerbosityLevel.SILENT); m.set_linear_solver(ns.LinearSolverType.BICGSTAB)
+    for a, t in zip(inp["bc_attr"], inp["bc_type"]):
+        m.set_bc(int(a), ns.BCType.DIRICHLET if int(t) == 0 else ns.BCType.MIRROR, 0.0)
+    for name in ("D", "SigR", "NSF", "Chi", "SigS"):
+        getattr(m, "get_" + name)()[...] = inp[name]
+    m.BuildMatrices()
+    return m
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_call_sequences(seed):
+    rnd = random.Random(seed)
+    shape = rnd.choice([(14, 1, 1), (9, 8, 1), (7, 6, 5), (12, 10, 1), (6, 5, 6), (10, 4, 4)])
+    rt = rnd.choice([0, 0, 0, 1, 2]); p = rnd.randint(0, rt)
+    ng = rnd.choice([1, 2, 3])
+    inp = synthetic_inputs(*shape, ng=ng, seed=100 + seed, dirichlet=rnd.choice([(1, 2, 3, 4, 5, 6), (1, 2, 3, 5), (2, 4, 6)]))
+    o = make_oracle(inp, rt, p); o.set_linear_solver(6)
+    m = _module(inp, rt, p)
+    factors = [2 if n % 2 == 0 else 1 for n in shape][:o.dim]
+    log = []
+    tolf = 1e-5                                                  # module default tol_flux = CG tolerance (src/NeutFEM.cpp:113-300)
+    for step in range(7):
+        kthr, fthr = max(1e-9, 0.1 * tolf), max(1e-7, 5.0 * tolf)   # both sides stop on the same tests: agreement is tolerance-limited
+        op = rnd.choice(["solve", "solve", "solve", "reset", "tol", "xs", "adjoint", "coarse"])
+        log.append(op)
+        if op == "solve":
+            diag = rnd.random() < 0.4 and rt == 0
+            cmfd = diag and rnd.random() < 0.5               # CMFD only where its map is not rounding-chaotic (test_gpu_cmfd.py)
+            coarse = rnd.random() < 0.4
+            ko = o.SolveKeff(coarse, factors, diag, cmfd); km = m.SolveKeff(coarse, factors, diag, cmfd)
+            assert abs(km - ko) / abs(ko) < kthr, (seed, step, log, km, ko)
+            assert m.GetLastKeff() == km
+            assert rel_l2(m.get_flux().ravel(), o.get_flux().ravel()) < fthr, (seed, step, log)
+        elif op == "reset":
+            o.reset_flux(); m.reset_flux()
+        elif op == "tol":
+            t = rnd.choice([(1e-9, 1e-9, 1e-9, 400, 2000), (1e-10, 1e-10, 1e-10, 60, 3000), (1e-8, 1e-9, 1e-9, 25, 2000)])
+            o.set_tol(*t); m.set_tol(*t); tolf = t[1]
+        elif op == "xs":                                         # edit in place through the numpy views, then rebuild (:454-456)
+            f = 1.0 + 0.05 * rnd.random()
+            o.get_SigR()[...] *= f; m.get_SigR()[...] *= f
+            o.get_NSF()[0][...] *= 1.02; m.get_NSF()[0][...] *= 1.02
+            o.BuildMatrices(); m.BuildMatrices()
+        elif op == "adjoint":
+            ka_o = o.SolveAdjoint(True, True); ka_m = m.SolveAdjoint(True, True)
+            assert abs(ka_m - ka_o) / abs(ka_o) < kthr, (seed, step, log)
+            assert rel_l2(m.get_flux_adj().ravel(), o.get_flux_adj().ravel()) < 4 * fthr, (seed, step, log)
+        else:
+            kc_o, pc_o = o.SolveCoarse(factors); kc_m, pc_m = m.SolveCoarse(factors)
+            assert abs(kc_m - kc_o) / abs(kc_o) < 10 * kthr, (seed, step, log)      # coarse tolerances are x10 (:2460-2467)
+            assert rel_l2(np.asarray(pc_m).ravel(), pc_o.ravel()) < 10 * fthr, (seed, step, log)
+    o.set_tol(1e-10, 1e-10, 1e-10, 600, 3000); m.set_tol(1e-10, 1e-10, 1e-10, 600, 3000)
+    ko = o.SolveKeff(); km = m.SolveKeff()
+    assert abs(km - ko) / abs(ko) < 1e-9, (seed, log)
+    assert rel_l2(m.get_flux().ravel(), o.get_flux().ravel()) < 1e-7, (seed, log)
