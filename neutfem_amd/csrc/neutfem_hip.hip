@@ -513,12 +513,32 @@ int nf_upload_xs(nf_handle S, const double *D, const double *SigR, const double 
     for (int i = 0; i < ng * ng; ++i) {
         const double *blk = SigS + (size_t)i * S->N;
         bool nz = false;                                          // src/NeutFEM.cpp:1265 : |sigs| > 1e-14
-        for (long e = 0; e < S->N; ++e) if (std::fabs(blk[e]) > 1e-14) { nz = true; break; }
+        for (long e = 0; e < S->N; ++e) if (!(std::fabs(blk[e]) <= 1e-14)) { nz = true; break; }   // NaN counts as non-empty (flagged below)
         if (!nz) { dfree(S->d_SigS[i]); continue; }              // an empty block adds exact zeros: skipping it is equivalent (:1722)
         NFCHK(dalloc(&S->d_SigS[i], S->N));
         HIPCHK(hipMemcpyAsync(S->d_SigS[i], blk, S->N * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    // non-finite cross sections or D == 0 would only surface later as a NaN eigenvalue: refuse them here (checked on the device)
+    int *d_flags = nullptr, flags = 0;
+    NFCHK(dalloc(&d_flags, 1));
+    (void)hipMemsetAsync(d_flags, 0, sizeof(int), st);
+    const int gchk = grid_for((long)NN, 256, 4096);
+    hipLaunchKernelGGL(k_check_xs, dim3(gchk), dim3(256), 0, st, S->d_D, (long)NN, 1, 0, d_flags);
+    hipLaunchKernelGGL(k_check_xs, dim3(gchk), dim3(256), 0, st, S->d_SigR, (long)NN, 0, 1, d_flags);
+    hipLaunchKernelGGL(k_check_xs, dim3(gchk), dim3(256), 0, st, S->d_NSF, (long)NN, 0, 2, d_flags);
+    hipLaunchKernelGGL(k_check_xs, dim3(gchk), dim3(256), 0, st, S->d_Chi, (long)NN, 0, 3, d_flags);
+    for (int i = 0; i < ng * ng; ++i)
+        if (S->d_SigS[i]) hipLaunchKernelGGL(k_check_xs, dim3(grid_for(S->N, 256, 4096)), dim3(256), 0, st, S->d_SigS[i], S->N, 0, 4, d_flags);
+    hipError_t ce = hipMemcpyAsync(&flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+    dfree(d_flags);
+    if (ce != hipSuccess) return fail(NF_ERR_HIP, "nf_upload_xs: %s", hipGetErrorString(ce));
+    if (flags) {
+        static const char *names[5] = { "D (non-finite or zero)", "SigR", "NSF", "Chi", "SigS" };
+        std::string which;
+        for (int b = 0; b < 5; ++b) if (flags & (1 << b)) { if (!which.empty()) which += ", "; which += names[b]; }
+        return fail(NF_ERR_ARG, "nf_upload_xs: invalid cross sections: %s", which.c_str());
+    }
     S->xs_uploaded = true; S->built = false;
     return NF_OK;
 }

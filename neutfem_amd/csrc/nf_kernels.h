@@ -1312,6 +1312,18 @@ __global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ src, d
     for (; i < n2; i += stride) dst[i] = src[i];
 }
 
+// input validation on the device (nf_upload_xs): bit `bit` of *flags is raised if the array holds a non-finite value, or
+// (need_nonzero) an exact zero -- 1/D of such a cell would put inf into every line system it touches
+__global__ void k_check_xs(const double *__restrict__ v, long n, int need_nonzero, int bit, int *__restrict__ flags)
+{
+    bool bad = false;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const double x = v[i];
+        bad |= !isfinite(x) || (need_nonzero && x == 0.0);
+    }
+    if (bad) atomicOr(flags, 1 << bit);
+}
+
 // fill with a deterministic pseudo-random pattern (profiling helper)
 __global__ void k_fill_pattern(double *__restrict__ v, long n)
 {

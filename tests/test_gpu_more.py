@@ -70,6 +70,13 @@ def test_error_behaviour():
         s.solve_keff()
     with pytest.raises(RuntimeError, match="bad arguments"):
         s.schur_apply(7, np.zeros(s.n_phi))
+    bad = inp["D"].copy(); bad[1, 2, 3, 4] = 0.0                   # 1/D = inf
+    with pytest.raises(RuntimeError, match="invalid cross sections: D"):
+        s.upload_xs(bad, inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"])
+    bad = inp["SigS"].copy(); bad[0, 1, 0, 0, 0] = np.nan
+    with pytest.raises(RuntimeError, match="invalid cross sections: SigS"):
+        s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], bad)
+    s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"]); s.build()
     s.close()
     with pytest.raises(RuntimeError, match="out of range"):
         HipSolver(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], device=99)
