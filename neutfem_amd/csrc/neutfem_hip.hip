@@ -308,6 +308,9 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     for (int i = 0; i < S->nx; ++i) S->hx[i] = xb[i + 1] - xb[i];
     if (S->dim >= 2) for (int i = 0; i < S->ny; ++i) S->hy[i] = yb[i + 1] - yb[i];
     if (S->dim == 3) for (int i = 0; i < S->nz; ++i) S->hz[i] = zb[i + 1] - zb[i];
+    for (auto *h : { &S->hx, &S->hy, &S->hz })
+        for (double v : *h)
+            if (!(v > 0.0) || !std::isfinite(v)) { delete S; return fail(NF_ERR_ARG, "nf_create: mesh breaks must be finite and strictly increasing (cell width %g)", v); }
     {                                                            // src/FEM.cpp:177-259
         int nf = 1, ni = k; for (int t = 1; t < S->dim; ++t) { nf *= k + 1; ni *= k + 1; }
         S->nJx = (long)(S->nx + 1) * S->ny * S->nz * nf;

@@ -78,6 +78,8 @@ def test_error_behaviour():
         s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], bad)
     s.upload_xs(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"]); s.build()
     s.close()
+    with pytest.raises(RuntimeError, match="strictly increasing"):
+        HipSolver(0, 0, 2, np.array([0.0, 1.0, 1.0, 2.0]), inp["y_breaks"], inp["z_breaks"])
     with pytest.raises(RuntimeError, match="out of range"):
         HipSolver(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], device=99)
     long_x = np.linspace(0, 1, 4100)                               # beyond the 4096-cell x-line limit of the RT0 kernel
