@@ -135,7 +135,7 @@ int nf_solve_coarse(nf_handle h, const nf_keff_opts *opts, double *k_coarse, dou
 /* Sol_Phi_ / Sol_J_ (include/NeutFEM.hpp:380-388) and NeutFEM::ResetFlux (src/NeutFEM.cpp:347-354) */
 int nf_set_phi(nf_handle h, const double *phi_host);
 int nf_get_phi(nf_handle h, double *phi_host);
-int nf_get_J(nf_handle h, double *J_host);
+int nf_get_J(nf_handle h, double *J_host);   /* on a slab: the slab's own faces (shared interface planes appear in both neighbours); collective */
 int nf_reset_flux(nf_handle h);
 int nf_set_warm_state(nf_handle h, int has_valid_keff, double last_keff);
 int nf_get_warm_state(nf_handle h, int *has_valid_keff, double *last_keff);

@@ -344,6 +344,19 @@ class HipTeam:
     def time_schur_apply(self, g, reps): return self.head.time_schur_apply(g, reps)
     def synchronize(self): self.head._chk(self.L.nf_synchronize(self.head.h))
 
+    def get_J_local(self):
+        """Sol_J_ of the local slabs assembled over their planes: (ng, n_J of the stacked local slabs) in the reference's
+        face numbering (x faces, y faces, z faces).  Collective on a multi-rank run (the z currents cross slabs)."""
+        nx, ny, ng = self.head.nx, self.head.ny, self.ng
+        xs, ys, zs = [], [], []
+        for i, s in enumerate(self.slabs):
+            J = s.get_J()
+            nxf, nyf, nzf = (nx + 1) * ny * s.nz, nx * (ny + 1) * s.nz, nx * ny * (s.nz + 1)
+            xs.append(J[:, :nxf]); ys.append(J[:, nxf:nxf + nyf])
+            z = J[:, nxf + nyf:nxf + nyf + nzf].reshape(ng, s.nz + 1, ny * nx)
+            zs.append(z if i == len(self.slabs) - 1 else z[:, :-1])      # the shared interface plane is reported by both neighbours
+        return np.concatenate([np.concatenate(xs, axis=1), np.concatenate(ys, axis=1), np.concatenate(zs, axis=1).reshape(ng, -1)], axis=1)
+
     def get_phi_local(self):
         """(ng, local planes, ny, nx)"""
         return np.concatenate([s.get_phi().reshape(self.ng, s.nz, s.ny, s.nx) for s in self.slabs], axis=1)

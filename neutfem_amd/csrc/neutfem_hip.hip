@@ -144,6 +144,7 @@ struct nf_solver {
     double *d_tf = nullptr, *d_rhs = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
     bool raw_valid = false, raw_is_diag = false;
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
+    double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nx*ny*(nz+1) (nf_get_J)
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
     bool cmfd_init = false; double cmfd_relax = 1.0;
     double *d_Dt[3] = {nullptr, nullptr, nullptr}, *d_Dh[3] = {nullptr, nullptr, nullptr}; long nfc[3] = {0, 0, 0};
@@ -382,7 +383,7 @@ int nf_destroy(nf_handle S)
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
-    dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
+    dfree(S->d_Jz); dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
     dfree(S->d_phi); dfree(S->d_raw); dfree(S->d_p0); dfree(S->d_p1);
     dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q);
     if (T) {
@@ -815,6 +816,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
         const long nl = S->nlines[2];
         sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
         sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
+        sa.jz = zmode == 3 ? S->d_Jz + (size_t)g * nl * (S->nz + 1) : nullptr;
         NF_S_SEG(2, true, 0);
     } else if (d == 1) {
         if (S->nb == 0) NF_S_SEG(1, false, 0); else if (S->nb == 1) NF_S_SEG(1, false, 1); else NF_S_SEG(1, false, 2);
@@ -823,6 +825,43 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     }
 #undef NF_S_SEG
 #undef NF_S
+    return NF_OK;
+}
+
+// Partition method, first half (slab teams): the endpoint pass of every slab (mode 1), the plane exchange and the separator
+// values (+ Jacobi sweeps for thin slabs).  The exchange and the separator kernels run on the comm stream; ev_xchg marks
+// their end -- the caller's z pass (or current reconstruction) waits for it, the x / y passes do not.
+static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double *> &xs, const std::vector<double *> &ys, const CgScalars *cg,
+                               hipEvent_t after_z1)
+{
+    const int ns = (int)T->slabs.size();
+    for (int i = 0; i < ns; ++i) {
+        nf_solver *S = T->slabs[i];
+        if (!(S->if_lo || S->if_hi)) continue;
+        NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, cg, nullptr, 1));
+    }
+    if (after_z1) (void)hipEventRecord(after_z1, T->stream);
+    HIPCHK(hipEventRecord(T->ev_z1, T->stream));
+    HIPCHK(hipStreamWaitEvent(T->comm_stream, T->ev_z1, 0));
+    NFCHK(exchange_planes(T, 0, 0, T->comm_stream));
+    auto each_slab = [&](auto &&launch) {
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            if (S->if_lo || S->if_hi) launch(S, S->nlines[2], dim3((unsigned)((S->nlines[2] + 255) / 256)));
+        }
+    };
+    each_slab([&](nf_solver *S, long nl, dim3 gr) {
+        hipLaunchKernelGGL(k_separators, gr, dim3(256), 0, T->comm_stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi, S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl,
+                           S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, S->if_lo, S->if_hi, cg); });
+    for (int sweep = 0; sweep < T->sep_sweeps; ++sweep) {
+        each_slab([&](nf_solver *S, long nl, dim3 gr) {
+            hipLaunchKernelGGL(k_sep_couple, gr, dim3(256), 0, T->comm_stream, S->d_gfl + g * nl, S->d_ulo, S->d_uhi, S->d_elo, S->d_ehi, nl, S->if_lo, S->if_hi, cg); });
+        NFCHK(exchange_planes(T, 2, 0, T->comm_stream));
+        each_slab([&](nf_solver *S, long nl, dim3 gr) {
+            hipLaunchKernelGGL(k_sep_update, gr, dim3(256), 0, T->comm_stream, S->d_ctlo, S->d_cthi, S->d_elo, S->d_ehi, S->d_relo, S->d_rehi,
+                               S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg); });
+    }
+    HIPCHK(hipEventRecord(T->ev_xchg, T->comm_stream));
     return NF_OK;
 }
 
@@ -838,35 +877,7 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
     if (T->profile) prof_begin(T, 3, &ta, &tb);
     if (any_if) {                                                 // partition method step 1 + interface exchange
         if (T->profile) prof_begin(T, 4, &a, &b);
-        for (int i = 0; i < ns; ++i) {
-            nf_solver *S = T->slabs[i];
-            if (!(S->if_lo || S->if_hi)) continue;
-            NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, cg, nullptr, 1));
-        }
-        if (T->profile) (void)hipEventRecord(b, T->stream);
-        // the planes travel on the comm stream while the x and y passes run; the z pass waits for them (ev_xchg)
-        HIPCHK(hipEventRecord(T->ev_z1, T->stream));
-        HIPCHK(hipStreamWaitEvent(T->comm_stream, T->ev_z1, 0));
-        NFCHK(exchange_planes(T, 0, 0, T->comm_stream));
-        // separator values (+ Jacobi sweeps for thin slabs), still on the comm stream, still behind the x / y passes
-        auto each_slab = [&](auto &&launch) {
-            for (int i = 0; i < ns; ++i) {
-                nf_solver *S = T->slabs[i];
-                if (S->if_lo || S->if_hi) launch(S, S->nlines[2], dim3((unsigned)((S->nlines[2] + 255) / 256)));
-            }
-        };
-        each_slab([&](nf_solver *S, long nl, dim3 gr) {
-            hipLaunchKernelGGL(k_separators, gr, dim3(256), 0, T->comm_stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi, S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl,
-                               S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, S->if_lo, S->if_hi, cg); });
-        for (int sweep = 0; sweep < T->sep_sweeps; ++sweep) {
-            each_slab([&](nf_solver *S, long nl, dim3 gr) {
-                hipLaunchKernelGGL(k_sep_couple, gr, dim3(256), 0, T->comm_stream, S->d_gfl + g * nl, S->d_ulo, S->d_uhi, S->d_elo, S->d_ehi, nl, S->if_lo, S->if_hi, cg); });
-            NFCHK(exchange_planes(T, 2, 0, T->comm_stream));
-            each_slab([&](nf_solver *S, long nl, dim3 gr) {
-                hipLaunchKernelGGL(k_sep_update, gr, dim3(256), 0, T->comm_stream, S->d_ctlo, S->d_cthi, S->d_elo, S->d_ehi, S->d_relo, S->d_rehi,
-                                   S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg); });
-        }
-        HIPCHK(hipEventRecord(T->ev_xchg, T->comm_stream));
+        NFCHK(team_endpoint_phase(T, g, xs, ys, cg, T->profile ? b : nullptr));
     }
     for (int d = 0; d < dim; ++d) {
         const int last = d == dim - 1;
@@ -1094,14 +1105,45 @@ int nf_reset_flux(nf_handle S)
 int nf_set_warm_state(nf_handle S, int v, double k) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->team->has_valid_keff = v; S->team->last_keff = k; return NF_OK; }
 int nf_get_warm_state(nf_handle S, int *v, double *k) { if (!S) return fail(NF_ERR_ARG, "null handle"); if (v) *v = S->team->has_valid_keff; if (k) *k = S->team->last_keff; return NF_OK; }
 
+// z currents of every local slab from the raw group fluxes of the last solve: endpoint pass, exchange, separators, then the
+// chain solve in "emit" mode (k_schur_s mode 3).  Cached until the next solve.
+static int team_reconstruct_Jz(nf_team *T)
+{
+    bool all = true; for (auto *S : T->slabs) all &= S->jz_valid;
+    if (all) return NF_OK;
+    NFCHK(team_prepare(T));
+    const int ns = (int)T->slabs.size(), ng = T->slabs[0]->ng;
+    for (auto *S : T->slabs) if (!S->d_Jz) NFCHK(dalloc(&S->d_Jz, (size_t)S->nJz * ng));
+    std::vector<const double *> xs(ns); std::vector<double *> ys(ns);
+    for (int g = 0; g < ng; ++g) {
+        for (int i = 0; i < ns; ++i) { xs[i] = T->slabs[i]->d_raw + (size_t)g * T->slabs[i]->nphi; ys[i] = T->slabs[i]->d_q; }
+        NFCHK(team_endpoint_phase(T, g, xs, ys, nullptr, nullptr));
+        HIPCHK(hipStreamWaitEvent(T->stream, T->ev_xchg, 0));
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i];
+            NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, nullptr, nullptr, 3));
+        }
+        HIPCHK(hipStreamSynchronize(T->stream));                  // the exchange buffers are reused by the next group
+    }
+    HIPCHK(hipGetLastError());
+    for (auto *S : T->slabs) S->jz_valid = true;
+    return NF_OK;
+}
+
 int nf_get_J(nf_handle S, double *J_host)
 {
     if (!S || !J_host) return fail(NF_ERR_ARG, "nf_get_J: bad arguments");
-    if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "nf_get_J is not available on a slab (currents are reconstructed on undivided meshes only)");
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const long N = S->N, nJ = S->nJ;
     if (!S->raw_valid) { memset(J_host, 0, sizeof(double) * nJ * S->ng); return NF_OK; }   // Sol_J_ = 0 before any solve
+    const bool slab = S->if_lo || S->if_hi;
+    if (slab) {
+        // z currents cross slabs: one partition-method solve per group on the raw group fluxes, for the whole team (collective:
+        // every rank calls nf_get_J on its slabs in the same order; the first call after a solve does the work for all local slabs)
+        if (S->raw_is_diag) return fail(NF_ERR_UNSUPPORTED, "nf_get_J on a slab after a diagonal-Schur solve is not available");
+        NFCHK(team_reconstruct_Jz(S->team));
+    }
     double *dJ = nullptr; NFCHK(dalloc(&dJ, (size_t)nJ));
     Geom G = make_geom(S);
     int nfa = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nfa *= S->k + 1; ni *= S->k + 1; }
@@ -1109,7 +1151,7 @@ int nf_get_J(nf_handle S, double *J_host)
     const long foff[3] = { 0, S->nJx, S->nJx + S->nJy };
     for (int g = 0; g < S->ng; ++g) {
         HIPCHK(hipMemsetAsync(dJ, 0, (size_t)nJ * sizeof(double), st));                     // modes that see no phi moment stay 0
-        for (int d = 0; d < S->dim; ++d)
+        for (int d = 0; d < (slab ? 2 : S->dim); ++d)
             for (int mode = 0; mode < n_modes(S); ++mode) {
                 ModeArgs ma = mode_args(S, g, d, mode, S->d_raw + (size_t)g * S->nphi, S->d_raw + (size_t)g * S->nphi);
                 // transverse mode index in the RT numbering: a = sum a_t (k+1)^t over the transverse axes (FEM.cpp:364-374)
@@ -1119,6 +1161,7 @@ int nf_get_J(nf_handle S, double *J_host)
                                    S->d_D + g * N, S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * S->nlines[d],
                                    dJ + foff[d], dJ + nJface + (long)d * N * ni, S->nlines[d], S->raw_is_diag ? 1 : 0);
             }
+        if (slab) HIPCHK(hipMemcpyAsync(dJ + foff[2], S->d_Jz + (size_t)g * S->nJz, S->nJz * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(J_host + (size_t)g * nJ, dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
@@ -1487,7 +1530,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     HIPCHK(hipGetLastError());
     if (T->profile) prof_collect(T);
     T->profile = false;
-    for (auto *S : T->slabs) { S->raw_valid = T->last_outer > 0; S->raw_is_diag = use_diag != 0; }
+    for (auto *S : T->slabs) { S->raw_valid = T->last_outer > 0; S->raw_is_diag = use_diag != 0; S->jz_valid = false; }
     T->has_valid_keff = 1; T->last_keff = keff;                   // :1808-1809
     if (keff_out) *keff_out = keff;
     if (n_outer) *n_outer = T->last_outer;

@@ -553,11 +553,13 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
 // slab-local line.  mode 1 = endpoint response (partition method, step 1): solve with the plain
 // neighbour cells as boundary data, emit c_lo = -x_edge - a_lo u_first, c_hi = x_edge - a_hi u_last,
 // touch no y.  mode 2 = final solve with the separator values u_lo/u_hi folded into the boundary data,
-// accumulate y on the chain cells and on the edge cells.
+// accumulate y on the chain cells and on the edge cells.  mode 3 = the same solve, but instead of y it stores the face
+// unknowns themselves, negated: the z currents of the slab (current reconstruction on decomposed meshes).
 struct SlabArgs {
     int if_lo, if_hi, mode, xcd;
     const double *alo, *ahi, *ulo, *uhi;      // per line
     double *clo, *chi;                        // per line (mode 1 outputs)
+    double *jz;                               // mode 3: J = -u on the slab's own z faces [(face) * nx * ny + line] (Sol_J_, src/solvers.cpp:228)
 };
 template <int SEG, int DIR, bool SLAB, int NB>
 __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
@@ -602,13 +604,13 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                 a_lo = sa.alo[lineid]; x_before = x[edge_lo];
                 if (fuse) { if (seg == 0) fz.xsol[edge_lo] += f_alpha * x_before; x_before = fz.r[edge_lo] + f_beta * x_before; }
                 xe_lo = x_before;
-                if (sa.mode == 2) { u_lo = sa.ulo[lineid]; x_before -= a_lo * u_lo; }
+                if (sa.mode >= 2) { u_lo = sa.ulo[lineid]; x_before -= a_lo * u_lo; }
             }
             if (sa.if_hi) {
                 a_hi = sa.ahi[lineid]; x_after = x[edge_hi];
                 if (fuse) { if (seg == 0) fz.xsol[edge_hi] += f_alpha * x_after; x_after = fz.r[edge_hi] + f_beta * x_after; }
                 xe_hi = x_after;
-                if (sa.mode == 2) { u_hi = sa.uhi[lineid]; x_after += a_hi * u_hi; }
+                if (sa.mode >= 2) { u_hi = sa.uhi[lineid]; x_after += a_hi * u_hi; }
             }
         }
     }
@@ -714,6 +716,20 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                 }
             }
         }
+    }
+    if (SLAB && sa.mode == 3) {                                 // emit J_z = -u on every face of the local line
+        if (valid) {
+            const long nxy = sl;                                 // z lines: stride between planes = nx * ny
+            const int fs = sa.if_lo ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) if (c0 + i < n) sa.jz[(long)(fs + c0 + i + 1) * nxy + lineid] = -w[i];
+            if (seg == 0) {
+                sa.jz[(long)fs * nxy + lineid] = -ulo;           // lower face of the first chain cell
+                if (sa.if_lo) sa.jz[lineid] = -u_lo;             // the separators themselves
+                if (sa.if_hi) sa.jz[(long)(fs + n + 1) * nxy + lineid] = -u_hi;
+            }
+        }
+        return;
     }
     if (SLAB) {
         // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1

@@ -48,10 +48,21 @@ def main():
     k, n = t.solve_keff(True, [2, 1, 2], use_diag=bool(use_diag)) if not use_diag else t.solve_keff(use_diag=True)
     print(f"rank {rank}: k = {k:.12f} after {n} outers, {t.history()['cg'].sum()} CG iterations, {time.time() - t0:.1f} s", flush=True)
     phi = t.get_phi_local()
-    ys = [None] * world; ps = [None] * world; ks = [None] * world
+    J = t.get_J_local() if not use_diag else None                 # collective: the z currents cross slabs
+    ys = [None] * world; ps = [None] * world; ks = [None] * world; js = [None] * world
     dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n), ks if rank == 0 else None)
+    dist.gather_object((J, k1 - k0), js if rank == 0 else None)
     if rank == 0:
-        np.savez(out, y=np.concatenate(ys, axis=0), phi=np.concatenate(ps, axis=1), k=np.array([v[0] for v in ks]), n=np.array([v[1] for v in ks]), x=xg)
+        extra = {}
+        if not use_diag:                                          # global Sol_J_ from the ranks' pieces (x | y | z faces, planes stacked)
+            xs, ysf, zs = [], [], []
+            for r, (Jr, nzr) in enumerate(js):
+                nxf, nyf = (nx + 1) * ny * nzr, nx * (ny + 1) * nzr
+                xs.append(Jr[:, :nxf]); ysf.append(Jr[:, nxf:nxf + nyf])
+                z = Jr[:, nxf + nyf:].reshape(2, nzr + 1, ny * nx)
+                zs.append(z if r == world - 1 else z[:, :-1])
+            extra["J"] = np.concatenate([np.concatenate(xs, axis=1), np.concatenate(ysf, axis=1), np.concatenate(zs, axis=1).reshape(2, -1)], axis=1)
+        np.savez(out, y=np.concatenate(ys, axis=0), phi=np.concatenate(ps, axis=1), k=np.array([v[0] for v in ks]), n=np.array([v[1] for v in ks]), x=xg, **extra)
     dist.barrier()
     t.close()
     dist.destroy_process_group()

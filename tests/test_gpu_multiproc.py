@@ -69,6 +69,8 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     assert int(res["n"][0]) == ns == 16
     assert abs(res["k"][0] - ks) / ks < 1e-8
     assert rel_l2(res["phi"].ravel(), s.get_phi().ravel()) < 1e-6
+    if not use_diag:                                              # currents: z faces through the partition method across ranks
+        assert rel_l2(res["J"].ravel(), s.get_J().ravel()) < 1e-6
     s.close()
 
 

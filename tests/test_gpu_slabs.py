@@ -149,3 +149,22 @@ def test_team_diagonal_path_matches_oracle(planes):
         sinv = np.concatenate([s.diagonal_cache(g) for s in t.slabs])
         assert np.abs(sinv / o.diag_cache(g) - 1).max() < 1e-14
     t.close()
+
+
+@pytest.mark.parametrize("planes", [[(0, 40), (40, 80)], [(0, 9), (9, 20), (20, 31), (31, 40)]])
+def test_team_currents_match_oracle(planes):
+    """Sol_J_ on a decomposed mesh: x / y faces slab-locally, z faces through the partition method in emit mode (k_schur_s
+    mode 3), separators included; thick and thin slabs, against the oracle's J = -A^-1 B^T phi of the same solve"""
+    nz = planes[-1][1]
+    inp = synthetic_inputs(8, 6, nz, 2, seed=13, dirichlet=(1, 2, 4, 5, 6))
+    o, t = make_oracle(inp), make_team(inp, planes)
+    tol = (1e-12, 1e-11, 1e-11, 30, 3000)                          # fixed work: 30 outers, tight inner solves
+    o.set_tol(*tol); t.set_tol(*tol)
+    ko = o.SolveKeff(); kt, _ = t.solve_keff()
+    assert abs(kt - ko) / ko < 1e-9
+    J = t.get_J_local()
+    assert J.shape == (2, o.n_J)
+    assert rel_l2(J.ravel(), o.J_dofs().ravel()) < 1e-7
+    for lo, hi in ((0, o.info("n_Jx")), (o.info("n_Jx") + o.info("n_Jy"), o.n_J)):      # x faces and z faces separately
+        assert rel_l2(J[:, lo:hi].ravel(), o.J_dofs()[:, lo:hi].ravel()) < 1e-7
+    t.close()
