@@ -109,3 +109,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
     assert abs(d["keff_after_timed_steps"] - d1["keff_after_timed_steps"]) / d1["keff_after_timed_steps"] < 1e-6
+
+
+def test_bench_json_contract_single_rank():
+    """the one-line JSON of `python bench.py` (driver contract + the tier's roofline / cpu_baseline objects), on a small mesh"""
+    e = dict(os.environ); e["NEUTFEM_BENCH_N"] = "48"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample-iters", "3"],
+                       env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                       # ONE line on stdout; progress notes go to stderr
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["measured_copy"]["GBps"] > 1000
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert d["parity"]["pcm"] < 1.0 and d["parity"]["flux_rel_l2"] < 1e-8
+    assert len(d["other_configs"]) == 4 and all(c["pcm_vs_oracle"] < 1.0 for c in d["other_configs"])
