@@ -131,6 +131,11 @@ int nf_get_phi_adj(nf_handle h, double *phi_adj_host);
 /* NeutFEM::SolveCoarse (src/NeutFEM.cpp:2380-2611): returns k_coarse and the prolonged flux
  * (ng*n_phi doubles, host) without touching the fine solution. */
 int nf_solve_coarse(nf_handle h, const nf_keff_opts *opts, double *k_coarse, double *phi_host);
+/* the two halves of SolveCoarse on their own (undivided meshes): nf_coarsen returns a BUILT RT0-P0 handle on the mesh merged by
+ * (rx, ry, rz) with block-mean cross sections (src/NeutFEM.cpp:2409-2556; the caller solves and destroys it), nf_prolong
+ * injects the coarse handle's current flux into the fine handle's (piecewise constant, higher moments zero, :2585-2606) */
+int nf_coarsen(nf_handle h, int rx, int ry, int rz, nf_handle *coarse);
+int nf_prolong(nf_handle coarse, nf_handle fine);
 
 /* Sol_Phi_ / Sol_J_ (include/NeutFEM.hpp:380-388) and NeutFEM::ResetFlux (src/NeutFEM.cpp:347-354) */
 int nf_set_phi(nf_handle h, const double *phi_host);
@@ -147,6 +152,8 @@ int nf_get_history(nf_handle h, double *k, double *dk, double *dphi, int *cg, in
  * name in {"schur_x","schur_y","schur_z","schur_apply","schur_z1"}: number of timed launches and their total ms. */
 int nf_profile_get(nf_handle h, const char *name, long *count, double *total_ms);
 int nf_profile_reset(nf_handle h);
+/* the same counters, with the iteration counts of the last solve, as one JSON object */
+int nf_timers(nf_handle h, char *json_buf, size_t len);
 /* times `reps` back-to-back Schur applies on group g (random x) with HIP events; average ms per apply */
 int nf_time_schur_apply(nf_handle h, int g, int reps, double *avg_ms);
 /* HBM microbenchmark: `reps` device-to-device streaming copies of `bytes` (read + write counted) -> GB/s; the

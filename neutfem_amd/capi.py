@@ -14,7 +14,7 @@ SYMBOLS = [
     "nf_last_error", "nf_device_count", "nf_create", "nf_destroy", "nf_create_slab", "nf_link_slabs", "nf_comm_unique_id",
     "nf_comm_init", "nf_comm_selftest", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
-    "nf_solve_coarse", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
+    "nf_solve_coarse", "nf_coarsen", "nf_prolong", "nf_timers", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy",
     "nf_set_option", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
@@ -65,6 +65,9 @@ def load():
     L.nf_set_phi.argtypes = [vp, dp]
     L.nf_get_phi.argtypes = [vp, dp]
     L.nf_get_J.argtypes = [vp, dp]
+    L.nf_coarsen.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.nf_prolong.argtypes = [vp, vp]
+    L.nf_timers.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.nf_initialize_cmfd.argtypes = [vp]
     L.nf_set_cmfd_relaxation.argtypes = [vp, C.c_double]
     L.nf_get_cmfd_coefficients.argtypes = [vp, C.c_int, C.c_int, dp, dp]
@@ -200,6 +203,26 @@ class HipSolver:
         k, n = C.c_double(), C.c_int()
         self._chk(self.L.nf_solve_keff(self.h, C.byref(o), C.byref(k), C.byref(n)))
         return k.value, n.value
+
+    def coarsen(self, rx, ry=1, rz=1):
+        """built coarse twin (HipSolver over the merged mesh, block-mean XS); close() it when done"""
+        h = C.c_void_p()
+        self._chk(self.L.nf_coarsen(self.h, rx, ry, rz, C.byref(h)))
+        c = HipSolver.__new__(HipSolver)
+        c.L, c.h = self.L, h
+        c.tol, c.solver_type, c.solver_pushed = self.tol, self.solver_type, self.solver_pushed
+        for key in ("dim", "nx", "ny", "nz", "ne", "ng", "n_phi", "n_J"):
+            setattr(c, key, c.L.nf_info(c.h, key.encode()))
+        c.n_loc = c.L.nf_info(c.h, b"n_loc")
+        return c
+
+    def prolong_from(self, coarse): self._chk(self.L.nf_prolong(coarse.h, self.h))
+
+    def timers(self):
+        import json
+        buf = C.create_string_buffer(2048)
+        self._chk(self.L.nf_timers(self.h, buf, 2048))
+        return json.loads(buf.value.decode())
 
     def initialize_cmfd(self): self._chk(self.L.nf_initialize_cmfd(self.h))
     def set_cmfd_relaxation(self, omega): self._chk(self.L.nf_set_cmfd_relaxation(self.h, float(omega)))

@@ -1173,6 +1173,37 @@ int nf_get_J(nf_handle S, double *J_host)
 // ---- SolveCoarse (src/NeutFEM.cpp:2380-2611) ---------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff, int *n_outer);
 
+// coarse twin of one slab (src/NeutFEM.cpp:2409-2556): every (rx, ry, rz) block of cells becomes one RT0-P0 cell, cross sections
+// are arithmetic volume-weighted block means, boundary conditions and interface flags carry over; returned built.
+static int coarsen_slab(nf_solver *S, int rx, int ry, int rz, nf_handle *out)
+{
+    const int dim = S->dim, ng = S->ng;
+    hipStream_t st = S->team->stream;
+    const int nxc = S->nx / rx, nyc = S->ny / ry, nzc = S->nz / rz;
+    std::vector<double> xc(nxc + 1), yc(dim >= 2 ? nyc + 1 : 1), zc(dim >= 3 ? nzc + 1 : 1);
+    for (int a = 0; a <= nxc; ++a) xc[a] = S->xb[a * rx];
+    if (dim >= 2) for (int j = 0; j <= nyc; ++j) yc[j] = S->yb[j * ry]; else yc[0] = 0.0;
+    if (dim >= 3) for (int kk = 0; kk <= nzc; ++kk) zc[kk] = S->zb[kk * rz]; else zc[0] = 0.0;
+    nf_handle C = nullptr;
+    NFCHK(create_impl(0, 0, ng, nxc + 1, xc.data(), (int)yc.size(), yc.data(), (int)zc.size(), zc.data(), S->if_lo, S->if_hi, S->device, &C));
+    *out = C;
+    for (int a = 0; a < 8; ++a) if (S->bc_set[a]) nf_set_bc(C, a, S->bc_type[a]);
+    const long Nc = C->N;
+    auto coarsen = [&](const double *fine, double **coarse, int nfields) -> int {
+        NFCHK(dalloc(coarse, (size_t)Nc * nfields));
+        hipLaunchKernelGGL(k_coarsen, dim3((unsigned)((Nc + 127) / 128)), dim3(128), 0, st, fine, *coarse, S->d_xb, S->d_yb, S->d_zb,
+                           dim, S->nx, S->ny, S->nz, rx, ry, rz, nfields);
+        return NF_OK;
+    };
+    NFCHK(coarsen(S->d_D, &C->d_D, ng)); NFCHK(coarsen(S->d_SigR, &C->d_SigR, ng));
+    NFCHK(coarsen(S->d_NSF, &C->d_NSF, ng)); NFCHK(coarsen(S->d_Chi, &C->d_Chi, ng));
+    for (int b = 0; b < ng * ng; ++b)
+        if (S->d_SigS[b]) NFCHK(coarsen(S->d_SigS[b], &C->d_SigS[b], 1));        // mean of an all-zero block is zero
+    HIPCHK(hipStreamSynchronize(st));
+    C->xs_uploaded = true;
+    return nf_build(C);
+}
+
 // Builds + solves the coarse problem on the device (every local slab coarsens its own planes; the coarse slabs form a
 // team that shares the fine team's communicator); the prolonged flux of slab i is written to dsts[i] (ng*nphi).
 static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, const std::vector<double *> &dsts, bool *done)
@@ -1203,32 +1234,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     }
     std::vector<nf_handle> C(ns, nullptr);
     int rc = NF_OK;
-    for (int i = 0; i < ns && rc == NF_OK; ++i) {
-        nf_solver *S = T->slabs[i];
-        const int nxc = S->nx / rx, nyc = S->ny / ry, nzc = S->nz / rz;
-        std::vector<double> xc(nxc + 1), yc(dim >= 2 ? nyc + 1 : 1), zc(dim >= 3 ? nzc + 1 : 1);
-        for (int a = 0; a <= nxc; ++a) xc[a] = S->xb[a * rx];
-        if (dim >= 2) for (int j = 0; j <= nyc; ++j) yc[j] = S->yb[j * ry]; else yc[0] = 0.0;
-        if (dim >= 3) for (int kk = 0; kk <= nzc; ++kk) zc[kk] = S->zb[kk * rz]; else zc[0] = 0.0;
-        rc = create_impl(0, 0, ng, nxc + 1, xc.data(), (int)yc.size(), yc.data(), (int)zc.size(), zc.data(), S->if_lo, S->if_hi, S->device, &C[i]);
-        if (rc != NF_OK) break;
-        for (int a = 0; a < 8; ++a) if (S->bc_set[a]) nf_set_bc(C[i], a, S->bc_type[a]);
-        const long Nc = C[i]->N;
-        auto coarsen = [&](const double *fine, double **coarse, int nfields) -> int {
-            NFCHK(dalloc(coarse, (size_t)Nc * nfields));
-            hipLaunchKernelGGL(k_coarsen, dim3((unsigned)((Nc + 127) / 128)), dim3(128), 0, T->stream, fine, *coarse, S->d_xb, S->d_yb, S->d_zb,
-                               dim, S->nx, S->ny, S->nz, rx, ry, rz, nfields);
-            return NF_OK;
-        };
-        rc = coarsen(S->d_D, &C[i]->d_D, ng);
-        if (rc == NF_OK) rc = coarsen(S->d_SigR, &C[i]->d_SigR, ng);
-        if (rc == NF_OK) rc = coarsen(S->d_NSF, &C[i]->d_NSF, ng);
-        if (rc == NF_OK) rc = coarsen(S->d_Chi, &C[i]->d_Chi, ng);
-        for (int b = 0; b < ng * ng && rc == NF_OK; ++b)
-            if (S->d_SigS[b]) rc = coarsen(S->d_SigS[b], &C[i]->d_SigS[b], 1);    // mean of an all-zero block is zero
-        if (rc == NF_OK && hipStreamSynchronize(T->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "coarsen failed");
-        if (rc == NF_OK) { C[i]->xs_uploaded = true; rc = nf_build(C[i]); }
-    }
+    for (int i = 0; i < ns && rc == NF_OK; ++i) rc = coarsen_slab(T->slabs[i], rx, ry, rz, &C[i]);
     if (rc == NF_OK && ns > 1) rc = nf_link_slabs(C.data(), ns);
     nf_team *CT = rc == NF_OK ? C[0]->team : nullptr;
     if (CT) { CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false; }
@@ -1363,6 +1369,55 @@ static int cmfd_step(nf_solver *S, double keff, int use_diag)
         hipLaunchKernelGGL(k_cmfd_correct, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, S->d_raw + (size_t)g * NP, N, S->nloc, S->cmfd_relax);
     }
     HIPCHK(hipGetLastError());
+    return NF_OK;
+}
+
+// the two halves of SolveCoarse as separate entry points (undivided meshes): a built coarse handle, and the injection of its
+// flux into the fine handle's current flux (piecewise constant, higher moments zero, :2585-2606)
+int nf_coarsen(nf_handle S, int rx, int ry, int rz, nf_handle *coarse)
+{
+    if (!S || !coarse || rx < 1 || ry < 1 || rz < 1) return fail(NF_ERR_ARG, "nf_coarsen: bad arguments");
+    if (!S->xs_uploaded) return fail(NF_ERR_STATE, "nf_coarsen: call nf_upload_xs first");
+    if (!team_is_single(S->team)) return fail(NF_ERR_UNSUPPORTED, "nf_coarsen works on an undivided mesh (slab teams coarsen inside nf_solve_keff)");
+    if (S->dim < 2) ry = 1;
+    if (S->dim < 3) rz = 1;
+    if (S->nx % rx || S->ny % ry || S->nz % rz) return fail(NF_ERR_ARG, "coarse factors (%d,%d,%d) do not divide the mesh %d x %d x %d", rx, ry, rz, S->nx, S->ny, S->nz);
+    HIPCHK(hipSetDevice(S->device));
+    *coarse = nullptr;
+    int rc = coarsen_slab(S, rx, ry, rz, coarse);
+    if (rc != NF_OK && *coarse) { std::string keep = g_err; nf_destroy(*coarse); *coarse = nullptr; g_err = keep; }
+    return rc;
+}
+int nf_prolong(nf_handle C, nf_handle S)
+{
+    if (!C || !S) return fail(NF_ERR_ARG, "nf_prolong: null handle");
+    if (C->ng != S->ng || C->dim != S->dim || C->nloc != 1 || C->nx < 1 || S->nx % C->nx || S->ny % C->ny || S->nz % C->nz || C->device != S->device)
+        return fail(NF_ERR_ARG, "nf_prolong: %d x %d x %d is not a coarsening of %d x %d x %d (same device, groups, dimension; RT0-P0 coarse mesh)", C->nx, C->ny, C->nz, S->nx, S->ny, S->nz);
+    HIPCHK(hipSetDevice(S->device));
+    hipStream_t st = S->team->stream;
+    HIPCHK(hipStreamSynchronize(C->team->stream));
+    HIPCHK(hipMemsetAsync(S->d_phi, 0, (size_t)S->nphi * S->ng * sizeof(double), st));
+    hipLaunchKernelGGL(k_prolong, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, st, C->d_phi, S->d_phi, S->nx, S->ny, S->nz,
+                       S->nx / C->nx, S->ny / C->ny, S->nz / C->nz, S->ng, S->nphi);
+    HIPCHK(hipStreamSynchronize(st));
+    return NF_OK;
+}
+// counters and timers of the last solve as one JSON object (profiling slots of nf_profile_get, iteration counts)
+int nf_timers(nf_handle S, char *buf, size_t len)
+{
+    if (!S || !buf || len < 2) return fail(NF_ERR_ARG, "nf_timers: bad arguments");
+    nf_team *T = S->team;
+    std::string js = "{";
+    char tmp[160];
+    for (const char *nm : SLOT_NAMES) {
+        const ProfSlot &sl = T->prof[nm];
+        snprintf(tmp, sizeof tmp, "\"%s\": {\"count\": %ld, \"ms\": %.6f, \"skipped_noop\": %ld}, ", nm, sl.count, sl.ms, sl.skipped);
+        js += tmp;
+    }
+    snprintf(tmp, sizeof tmp, "\"last_outer\": %d, \"coarse_outer\": %d, \"last_cg_total\": %ld, \"separator_sweeps\": %d}", T->last_outer, T->coarse_outer, T->last_cg_total, T->sep_sweeps);
+    js += tmp;
+    if (js.size() + 1 > len) return fail(NF_ERR_ARG, "nf_timers: buffer of %zu bytes is too small (%zu needed)", len, js.size() + 1);
+    memcpy(buf, js.c_str(), js.size() + 1);
     return NF_OK;
 }
 

@@ -120,3 +120,27 @@ def test_single_cell_axes(shape, rt):
     assert n == o.info("last_outer") and abs(ks - ko) / ko < 1e-11
     assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-10
     s.close()
+
+
+def test_coarsen_and_prolong_entry_points():
+    """nf_coarsen + nf_solve_keff(coarse) + nf_prolong + nf_solve_keff(fine) by hand = SolveKeff(use_coarse_init=True, factors)
+    (src/NeutFEM.cpp:1665-1670, 2380-2611: coarse tolerances x10, max_outer / 2, k seeded by the coarse k); nf_timers"""
+    inp = synthetic_inputs(12, 10, 8, 2, seed=31)
+    tol = (1e-9, 1e-9, 1e-9, 400, 2000)
+    a = make_hip(inp); a.set_tol(*tol)
+    ka, na = a.solve_keff(True, [2, 2, 2])
+    b = make_hip(inp); b.set_tol(*tol)
+    c = b.coarsen(2, 2, 2)
+    assert (c.nx, c.ny, c.nz, c.n_phi) == (6, 5, 4, 120)
+    c.set_linear_solver(6); c.set_tol(1e-8, 1e-8, 1e-8, 200, 2000)
+    kc, nc = c.solve_keff()
+    assert nc == a.history()["coarse_outer"]
+    b.prolong_from(c); b.set_warm_state(1, kc)
+    kb, nb = b.solve_keff()
+    assert nb == na and abs(kb - ka) / ka < 1e-13
+    assert rel_l2(b.get_phi().ravel(), a.get_phi().ravel()) < 1e-12
+    t = b.timers()
+    assert t["last_outer"] == nb and t["last_cg_total"] == int(b.history()["cg"].sum()) and "schur_x" in t
+    with pytest.raises(RuntimeError, match="do not divide"):
+        b.coarsen(5, 2, 2)
+    c.close(); a.close(); b.close()
