@@ -51,7 +51,7 @@ int nf_destroy(nf_handle h);
  * Collective calls (every rank, same order): nf_comm_init, nf_solve_keff, nf_build_diagonal_cache,
  * nf_team_schur_apply, nf_time_schur_apply.  Decisions that could differ between ranks (slab too thin for the
  * separator sweeps, coarse factors that do not divide a slab) are all-reduced first, so all ranks return the same
- * error.  RT0-P0 only; slabs need >= 4 z-planes (>= ~30 for the single-exchange fast path).
+ * error.  Any RTk-Pm order; slabs need >= 4 z-planes (>= ~30 for the single-exchange fast path).
  * NEUTFEM_RCCL_LIB overrides the RCCL library path (tests use a host-staged stand-in to run several ranks on one GPU). */
 int nf_create_slab(int rt_order, int p_order, int ng,
                    int nxb, const double *xb_host, int nyb, const double *yb_host, int nzb_slab, const double *zb_slab_host,

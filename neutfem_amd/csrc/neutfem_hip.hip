@@ -288,8 +288,6 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     if (!out || !xb || nxb < 2 || ng < 1 || ng > 64) return fail(NF_ERR_ARG, "nf_create: bad arguments");
     int k = std::min(rt_order, 2), m = std::min(p_order, 2);
     if (k < m) m = k;                                            // src/NeutFEM.cpp:149-169
-    if ((if_lo || if_hi) && (k != 0 || m != 0))
-        return fail(NF_ERR_UNSUPPORTED, "slab decomposition is implemented for RT0-P0 only (asked RT%d-P%d)", k, m);
     int ndev = nf_device_count();
     if (ndev <= 0) return fail(NF_ERR_NO_DEVICE, "nf_create: no HIP device visible (the gfx950 path has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(NF_ERR_ARG, "nf_create: device %d out of range (%d devices)", device, ndev);
@@ -346,7 +344,7 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     if (rc == NF_OK) rc = dalloc(&S->d_p, S->nphi);
     if (rc == NF_OK) rc = dalloc(&S->d_q, S->nphi);
     if (rc == NF_OK && (if_lo || if_hi)) {
-        const size_t nl = (size_t)S->nlines[2];
+        const size_t nl = (size_t)S->nlines[2] * n_modes(S);          // exchange planes: [transverse mode][line]
         double **arrs[] = { &S->d_clo, &S->d_chi, &S->d_rlo, &S->d_rhi, &S->d_ulo, &S->d_uhi, &S->d_ctlo, &S->d_cthi, &S->d_elo, &S->d_ehi, &S->d_relo, &S->d_rehi };
         for (auto a : arrs) if (rc == NF_OK) { rc = dalloc(a, nl); if (rc == NF_OK) (void)hipMemset(*a, 0, nl * sizeof(double)); }
     }
@@ -646,13 +644,13 @@ static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
     auto recv_hi = [&](nf_solver *S) { return which == 2 ? S->d_rehi : S->d_rhi; };
     for (int i = 0; i + 1 < ns; ++i) {                            // interfaces between local slabs
         nf_solver *A = T->slabs[i], *B = T->slabs[i + 1];
-        const size_t bytes = (size_t)A->nlines[2] * sizeof(double);
+        const size_t bytes = (size_t)A->nlines[2] * (which == 1 ? 1 : n_modes(A)) * sizeof(double);
         HIPCHK(hipMemcpyAsync(recv_lo(B), send_hi(A), bytes, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(recv_hi(A), send_lo(B), bytes, hipMemcpyDeviceToDevice, st));
     }
     nf_solver *bot = T->slabs.front(), *top = T->slabs.back();
     if (T->nproc > 1 && (bot->if_lo || top->if_hi)) {
-        const size_t cnt = (size_t)bot->nlines[2];
+        const size_t cnt = (size_t)bot->nlines[2] * (which == 1 ? 1 : n_modes(bot));
         NCCLCHK(g_rccl.GroupStart());
         if (bot->if_lo) {
             NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
@@ -800,7 +798,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     while (TX > 8 && TX * NSEG > 1024) TX >>= 1;
     if (TX * NSEG > 1024) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than 1024 threads per block", n);
     while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;                   // narrow meshes
-    const ModeTab mt = zmode != 0 ? ModeTab{ 1, { 1.0 }, { { 0 } } } : mode_tab(S, d);
+    const ModeTab mt = mode_tab(S, d);
     dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter, (unsigned)mt.n), block((unsigned)(TX * NSEG));
     if (nparts) *nparts = (int)(grid.x * grid.y * grid.z);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
@@ -808,7 +806,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     SlabArgs sa; memset(&sa, 0, sizeof sa);
     sa.xcd = T->opt_xcd;
     const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
-    const CgFuse fz = zmode == 1 ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
+    const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
 #define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
         else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
@@ -817,7 +815,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
         sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
         sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
         sa.jz = zmode == 3 ? S->d_Jz + (size_t)g * nl * (S->nz + 1) : nullptr;
-        NF_S_SEG(2, true, 0);
+        if (S->nb == 0) NF_S_SEG(2, true, 0); else if (S->nb == 1) NF_S_SEG(2, true, 1); else NF_S_SEG(2, true, 2);
     } else if (d == 1) {
         if (S->nb == 0) NF_S_SEG(1, false, 0); else if (S->nb == 1) NF_S_SEG(1, false, 1); else NF_S_SEG(1, false, 2);
     } else {
@@ -847,19 +845,19 @@ static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double
     auto each_slab = [&](auto &&launch) {
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
-            if (S->if_lo || S->if_hi) launch(S, S->nlines[2], dim3((unsigned)((S->nlines[2] + 255) / 256)));
+            if (S->if_lo || S->if_hi) launch(S, S->nlines[2], dim3((unsigned)((S->nlines[2] * n_modes(S) + 255) / 256)));
         }
     };
     each_slab([&](nf_solver *S, long nl, dim3 gr) {
         hipLaunchKernelGGL(k_separators, gr, dim3(256), 0, T->comm_stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi, S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl,
-                           S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, S->if_lo, S->if_hi, cg); });
+                           S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, nl * n_modes(S), S->if_lo, S->if_hi, cg); });
     for (int sweep = 0; sweep < T->sep_sweeps; ++sweep) {
         each_slab([&](nf_solver *S, long nl, dim3 gr) {
-            hipLaunchKernelGGL(k_sep_couple, gr, dim3(256), 0, T->comm_stream, S->d_gfl + g * nl, S->d_ulo, S->d_uhi, S->d_elo, S->d_ehi, nl, S->if_lo, S->if_hi, cg); });
+            hipLaunchKernelGGL(k_sep_couple, gr, dim3(256), 0, T->comm_stream, S->d_gfl + g * nl, S->d_ulo, S->d_uhi, S->d_elo, S->d_ehi, nl, nl * n_modes(S), S->if_lo, S->if_hi, cg); });
         NFCHK(exchange_planes(T, 2, 0, T->comm_stream));
         each_slab([&](nf_solver *S, long nl, dim3 gr) {
             hipLaunchKernelGGL(k_sep_update, gr, dim3(256), 0, T->comm_stream, S->d_ctlo, S->d_cthi, S->d_elo, S->d_ehi, S->d_relo, S->d_rehi,
-                               S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, S->if_lo, S->if_hi, cg); });
+                               S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl, S->d_ulo, S->d_uhi, nl, nl * n_modes(S), S->if_lo, S->if_hi, cg); });
     }
     HIPCHK(hipEventRecord(T->ev_xchg, T->comm_stream));
     return NF_OK;
@@ -957,7 +955,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     int batch = T->cg_batch > 0 ? T->cg_batch : (T->last_its[g] > 0 ? T->last_its[g] + 2 : 1), grow = 2;
     // fused variant (RT0-P0, undivided mesh): x_sol / p updates ride in the next x pass (k_schur_x, CgFuse)
     // (undivided mesh: in the x pass; slab teams: in the endpoint pass of the z lines, the first pass to read p)
-    const bool fused = T->opt_fuse != 0;                          // slab teams are RT0-P0; an undivided mesh fuses at any order
+    const bool fused = T->opt_fuse != 0 && (team_is_single(T) || T->slabs[0]->nloc == 1);   // undivided: any order (x pass); slab teams: P0 (z endpoint pass)
     for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
     int rc = NF_OK;
     while (launched < maxit && rc == NF_OK) {
@@ -1142,6 +1140,7 @@ int nf_get_J(nf_handle S, double *J_host)
         // z currents cross slabs: one partition-method solve per group on the raw group fluxes, for the whole team (collective:
         // every rank calls nf_get_J on its slabs in the same order; the first call after a solve does the work for all local slabs)
         if (S->raw_is_diag) return fail(NF_ERR_UNSUPPORTED, "nf_get_J on a slab after a diagonal-Schur solve is not available");
+        if (S->k != 0) return fail(NF_ERR_UNSUPPORTED, "nf_get_J on a slab is implemented for RT0 only");
         NFCHK(team_reconstruct_Jz(S->team));
     }
     double *dJ = nullptr; NFCHK(dalloc(&dJ, (size_t)nJ));

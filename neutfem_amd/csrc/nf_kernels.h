@@ -297,37 +297,41 @@ __global__ void k_factor_lines(Geom G, int d, const double *__restrict__ D, doub
 __global__ void k_separators(const double *__restrict__ clo, const double *__restrict__ chi, const double *__restrict__ rlo,
                              const double *__restrict__ rhi, const double *__restrict__ sinv_lo, const double *__restrict__ sinv_hi,
                              double *__restrict__ ulo, double *__restrict__ uhi, double *__restrict__ ctlo, double *__restrict__ cthi,
-                             long nlines, int if_lo, int if_hi, const CgScalars *__restrict__ cg)
+                             long nlines, long ntot, int if_lo, int if_hi, const CgScalars *__restrict__ cg)
 {
+    // entries: [transverse mode][line] (ntot = modes * nlines); S_red, G are per line (unit-scaled factors serve every mode)
     if (cg && cg->done) return;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= nlines) return;
-    if (if_lo) { const double c = rlo[i] + clo[i]; ctlo[i] = c; ulo[i] = c * sinv_lo[i]; }   // below's c_hi + own c_lo (same order on both sides)
-    if (if_hi) { const double c = chi[i] + rhi[i]; cthi[i] = c; uhi[i] = c * sinv_hi[i]; }   // own c_hi + above's c_lo
+    if (i >= ntot) return;
+    const long l = i % nlines;
+    if (if_lo) { const double c = rlo[i] + clo[i]; ctlo[i] = c; ulo[i] = c * sinv_lo[l]; }   // below's c_hi + own c_lo (same order on both sides)
+    if (if_hi) { const double c = chi[i] + rhi[i]; cthi[i] = c; uhi[i] = c * sinv_hi[l]; }   // own c_hi + above's c_lo
 }
 // what this slab contributes to its two separators through itself: to the upper one G u_lower, to the lower one G u_upper
 __global__ void k_sep_couple(const double *__restrict__ gfl, const double *__restrict__ ulo, const double *__restrict__ uhi,
-                             double *__restrict__ elo, double *__restrict__ ehi, long nlines, int if_lo, int if_hi,
+                             double *__restrict__ elo, double *__restrict__ ehi, long nlines, long ntot, int if_lo, int if_hi,
                              const CgScalars *__restrict__ cg)
 {
     if (cg && cg->done) return;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= nlines) return;
+    if (i >= ntot) return;
     const bool both = if_lo && if_hi;
-    if (if_hi) ehi[i] = both ? gfl[i] * ulo[i] : 0.0;
-    if (if_lo) elo[i] = both ? gfl[i] * uhi[i] : 0.0;
+    const double g = gfl[i % nlines];
+    if (if_hi) ehi[i] = both ? g * ulo[i] : 0.0;
+    if (if_lo) elo[i] = both ? g * uhi[i] : 0.0;
 }
 // u = ((c + e_from_below) + e_from_above) / S_red ; relo = the slab below's e_hi, rehi = the slab above's e_lo
 __global__ void k_sep_update(const double *__restrict__ ctlo, const double *__restrict__ cthi, const double *__restrict__ elo,
                              const double *__restrict__ ehi, const double *__restrict__ relo, const double *__restrict__ rehi,
                              const double *__restrict__ sinv_lo, const double *__restrict__ sinv_hi, double *__restrict__ ulo,
-                             double *__restrict__ uhi, long nlines, int if_lo, int if_hi, const CgScalars *__restrict__ cg)
+                             double *__restrict__ uhi, long nlines, long ntot, int if_lo, int if_hi, const CgScalars *__restrict__ cg)
 {
     if (cg && cg->done) return;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= nlines) return;
-    if (if_lo) ulo[i] = ((ctlo[i] + relo[i]) + elo[i]) * sinv_lo[i];
-    if (if_hi) uhi[i] = ((cthi[i] + ehi[i]) + rehi[i]) * sinv_hi[i];
+    if (i >= ntot) return;
+    const long l = i % nlines;
+    if (if_lo) ulo[i] = ((ctlo[i] + relo[i]) + elo[i]) * sinv_lo[l];
+    if (if_hi) uhi[i] = ((cthi[i] + ehi[i]) + rehi[i]) * sinv_hi[l];
 }
 // S_red^-1 from the two halves (own + neighbour's)
 __global__ void k_sred_inv(const double *__restrict__ own, const double *__restrict__ other, double *__restrict__ out, long n, int own_first)
@@ -566,14 +570,13 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                           int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz)
 {
-    static_assert(!(SLAB && NB > 0), "slabs are RT0-P0");
     extern __shared__ double sm[];
     if (cg && cg->done) return;
     const ModeArgs ma = select_mode(ma0, mt, blockIdx.z, NB + 1);
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
     // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread
-    const bool fuse = SLAB && sa.mode == 1 && fz.p != nullptr && cg->its > 0;
+    const bool fuse = SLAB && NB == 0 && sa.mode == 1 && fz.p != nullptr && cg->its > 0;
     const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
     double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
@@ -590,6 +593,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     const bool valid = ix < nx;
     long base = (long)by * outer_stride + ix;
     const long lineid = (long)by * nx + ix;
+    const long lm = SLAB ? (long)blockIdx.z * ((long)nx * gridDim.y) + lineid : 0;   // slab exchange planes: [mode][line]
     // slab chain: cells [fs, fs+n) of the local line; x just outside the chain is real data (edge cells)
     double x_before = 0.0, x_after = 0.0, a_lo = 0.0, a_hi = 0.0, u_lo = 0.0, u_hi = 0.0, xe_lo = 0.0, xe_hi = 0.0;
     long edge_lo = 0, edge_hi = 0;
@@ -600,17 +604,29 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
         edge_lo = base; edge_hi = base + (long)(nloc - 1) * sl;
         base += (long)fs * sl;
         if (valid) {
+            // the edge cells sit between a separator and the chain: towards the chain they contribute xR (lower edge) / xL (upper
+            // edge), towards the separator xL / xR -- for RT0 all four are the cell value itself
             if (sa.if_lo) {
                 a_lo = sa.alo[lineid]; x_before = x[edge_lo];
                 if (fuse) { if (seg == 0) fz.xsol[edge_lo] += f_alpha * x_before; x_before = fz.r[edge_lo] + f_beta * x_before; }
                 xe_lo = x_before;
-                if (sa.mode >= 2) { u_lo = sa.ulo[lineid]; x_before -= a_lo * u_lo; }
+                if (NB > 0) {
+                    const double g1 = ma.Gc[0] * ma.x[1][edge_lo], g2 = NB > 1 ? ma.Gc[1] * ma.x[2][edge_lo] : 0.0;
+                    xe_lo = x_before + ma.eL[0] * g1 + (NB > 1 ? ma.eL[1] * g2 : 0.0);            // xL: towards the separator below
+                    x_before = x_before - ma.eR[0] * g1 - (NB > 1 ? ma.eR[1] * g2 : 0.0);          // xR: towards the chain
+                }
+                if (sa.mode >= 2) { u_lo = sa.ulo[lm]; x_before -= a_lo * u_lo; }
             }
             if (sa.if_hi) {
                 a_hi = sa.ahi[lineid]; x_after = x[edge_hi];
                 if (fuse) { if (seg == 0) fz.xsol[edge_hi] += f_alpha * x_after; x_after = fz.r[edge_hi] + f_beta * x_after; }
                 xe_hi = x_after;
-                if (sa.mode >= 2) { u_hi = sa.uhi[lineid]; x_after += a_hi * u_hi; }
+                if (NB > 0) {
+                    const double g1 = ma.Gc[0] * ma.x[1][edge_hi], g2 = NB > 1 ? ma.Gc[1] * ma.x[2][edge_hi] : 0.0;
+                    xe_hi = x_after - ma.eR[0] * g1 - (NB > 1 ? ma.eR[1] * g2 : 0.0);             // xR: towards the separator above
+                    x_after = x_after + ma.eL[0] * g1 + (NB > 1 ? ma.eL[1] * g2 : 0.0);           // xL: towards the chain
+                }
+                if (sa.mode >= 2) { u_hi = sa.uhi[lm]; x_after += a_hi * u_hi; }
             }
         }
     }
@@ -638,10 +654,11 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                 x1[i] = v1; if (NB > 1) x2[i] = v2;
                 // cell coordinates for 1/c_e = D / factor_dir
                 int cx = ix, cy = 0, cz = 0;
-                if (DIR == 1) { cy = c; cz = by; } else { cy = by; cz = c; }
+                if (DIR == 1) { cy = c; cz = by; } else { cy = by; cz = c + ((SLAB && sa.if_lo) ? 1 : 0); }   // chain cell c is local cell fs + c
                 icv[i] = ok ? ma.D[a] / geom_factor(G, DIR, cx, cy, cz) : 0.0;
             } else {
                 xLn = xv[i] + ma.eL[0] * ma.Gc[0] * v1 + (NB > 1 ? ma.eL[1] * ma.Gc[1] * v2 : 0.0);
+                if (SLAB && valid && c == n) xLn = x_after;          // the cell above the chain is the upper edge cell (xL, separator folded in)
             }
         }
     }
@@ -734,15 +751,40 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     if (SLAB) {
         // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1
         if (valid && seg == 0 && sa.if_lo) {
-            if (sa.mode == 1) sa.clo[lineid] = -xe_lo - a_lo * ulo;
-            else { const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv; }
+            if (sa.mode == 1) sa.clo[lm] = -xe_lo - a_lo * ulo;
+            else {
+                const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv;
+                if (NB > 0) {                                    // bubbles of the edge cell: faces (separator, first chain face)
+                    const double ice = ma.D[edge_lo] / geom_factor(G, DIR, ix, (int)by, 0);
+#pragma unroll
+                    for (int l = 0; l < NB; ++l) {
+                        const double xb = ma.x[l + 1][edge_lo];
+                        const double v = ma.Gc[l] * xb * ma.iM[l] * ice - (ma.eL[l] * u_lo + ma.eR[l] * ulo);
+                        const double yb = ma.y[l + 1][edge_lo] + ma.Ta * ma.Gc[l] * v;
+                        ma.y[l + 1][edge_lo] = yb; dot += xb * yb;
+                    }
+                }
+            }
         }
         if (valid && sa.if_hi && c0 <= n - 1 && n - 1 < c0 + SEG) {
             double ulast = 0.0;
 #pragma unroll
             for (int i = 0; i < SEG; ++i) if (c0 + i == n - 1) ulast = w[i];
-            if (sa.mode == 1) sa.chi[lineid] = xe_hi - a_hi * ulast;
-            else { const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv; }
+            if (sa.mode == 1) sa.chi[lm] = xe_hi - a_hi * ulast;
+            else {
+                const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv;
+                if (NB > 0) {                                    // faces (last chain face, separator)
+                    const int fsz = sa.if_lo ? 1 : 0;
+                    const double ice = ma.D[edge_hi] / geom_factor(G, DIR, ix, (int)by, fsz + n);
+#pragma unroll
+                    for (int l = 0; l < NB; ++l) {
+                        const double xb = ma.x[l + 1][edge_hi];
+                        const double v = ma.Gc[l] * xb * ma.iM[l] * ice - (ma.eL[l] * ulast + ma.eR[l] * u_hi);
+                        const double yb = ma.y[l + 1][edge_hi] + ma.Ta * ma.Gc[l] * v;
+                        ma.y[l + 1][edge_hi] = yb; dot += xb * yb;
+                    }
+                }
+            }
         }
     }
     if (last && partials) {
