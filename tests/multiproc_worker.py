@@ -20,13 +20,14 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nx, ny, nz = 10, 8, planes * world * per
-    if len(sys.argv) > 8:
+    if len(sys.argv) > 8 and int(sys.argv[8]) > 0:
         nz = int(sys.argv[8])                                     # uneven split (e.g. 100 planes on 3 ranks = 33 / 34 / 33)
+    rt = int(sys.argv[9]) if len(sys.argv) > 9 else 0            # RT order (P = RT): higher orders exchange one plane per transverse mode
     inp = synthetic_inputs(nx, ny, nz, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
     allp = split_planes(nz, world * per)
     mine = allp[rank * per:(rank + 1) * per]
     k0, k1 = mine[0][0], mine[-1][1]
-    t = capi.HipTeam(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], mine, device=0, below=rank > 0, above=rank < world - 1)
+    t = capi.HipTeam(rt, rt, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], mine, device=0, below=rank > 0, above=rank < world - 1)
     t.set_linear_solver(6)
     for a, ty in zip(inp["bc_attr"], inp["bc_type"]):
         t.set_bc(int(a), int(ty))
@@ -40,21 +41,21 @@ def main():
     assert t.head.info("n_ranks") == world and t.head.info("rank") == rank
     # 1. distributed Schur apply
     xg = np.random.default_rng(4).standard_normal((nz, ny, nx))
-    y = t.schur_apply(1, xg[k0:k1])
+    y = t.schur_apply(1, xg[k0:k1]) if rt == 0 else np.zeros((k1 - k0, ny, nx))
     # 2. distributed power iteration (coarse-mesh start on the team, borrowed communicator)
     import time
     t.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)                        # fixed work: 16 fine outers (8 coarse) with tight inner solves
     t0 = time.time()
     k, n = t.solve_keff(True, [2, 1, 2], use_diag=bool(use_diag)) if not use_diag else t.solve_keff(use_diag=True)
     print(f"rank {rank}: k = {k:.12f} after {n} outers, {t.history()['cg'].sum()} CG iterations, {time.time() - t0:.1f} s", flush=True)
-    phi = t.get_phi_local()
-    J = t.get_J_local() if not use_diag else None                 # collective: the z currents cross slabs
+    phi = t.get_phi_local() if rt == 0 else np.concatenate([s.get_phi().reshape(2, -1) for s in t.slabs], axis=1)
+    J = t.get_J_local() if (not use_diag and rt == 0) else None                 # collective: the z currents cross slabs
     ys = [None] * world; ps = [None] * world; ks = [None] * world; js = [None] * world
     dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n), ks if rank == 0 else None)
     dist.gather_object((J, k1 - k0), js if rank == 0 else None)
     if rank == 0:
         extra = {}
-        if not use_diag:                                          # global Sol_J_ from the ranks' pieces (x | y | z faces, planes stacked)
+        if not use_diag and rt == 0:                              # global Sol_J_ from the ranks' pieces (x | y | z faces, planes stacked)
             xs, ysf, zs = [], [], []
             for r, (Jr, nzr) in enumerate(js):
                 nxf, nyf = (nx + 1) * ny * nzr, nx * (ny + 1) * nzr

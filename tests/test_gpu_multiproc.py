@@ -74,6 +74,20 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     s.close()
 
 
+def test_two_ranks_rt1p1(tmp_path):
+    """RT1-P1 across two real processes: four transverse modes per interface travel as one message"""
+    out = str(tmp_path / "res.npz")
+    bad, logs = _run_ranks(2, [out, 1, 0, 14, 0, 1], tmp_path)
+    assert bad is None, bad + "\n" + logs
+    res = np.load(out)
+    inp = synthetic_inputs(10, 8, 28, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
+    s = make_hip(inp, 1, 1); s.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)
+    ks, ns = s.solve_keff(True, [2, 1, 2])
+    assert int(res["n"][0]) == ns == 16 and abs(res["k"][0] - ks) / ks < 1e-8
+    assert rel_l2(res["phi"].ravel(), s.get_phi().ravel()) < 1e-6
+    s.close()
+
+
 def test_thin_slab_is_refused_by_every_rank(tmp_path):
     """a middle slab of 3 planes: the refusal is taken on the all-reduced maximum, so all three ranks raise the same error at
     the same point instead of one raising and two blocking in the next collective"""
