@@ -168,6 +168,8 @@ template <class T> static int dalloc(T **p, size_t n)
     return NF_OK;
 }
 template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+// scratch device buffer of one function call: released on every return path
+template <class T> struct DevTmp { T *p = nullptr; ~DevTmp() { if (p) (void)hipFree(p); } DevTmp() = default; DevTmp(const DevTmp &) = delete; DevTmp &operator=(const DevTmp &) = delete; };
 
 static const char *SLOT_NAMES[5] = { "schur_x", "schur_y", "schur_z", "schur_apply", "schur_z1" };
 
@@ -1069,7 +1071,7 @@ static int phi_transfer(nf_solver *S, double *host, bool to_device, double *dev 
         else HIPCHK(hipMemcpy(host, dev, NN * sizeof(double), hipMemcpyDeviceToHost));
         return NF_OK;
     }
-    double *tmp = nullptr; NFCHK(dalloc(&tmp, NN));
+    DevTmp<double> tmp_; NFCHK(dalloc(&tmp_.p, NN)); double *tmp = tmp_.p;
     if (to_device) HIPCHK(hipMemcpy(tmp, host, NN * sizeof(double), hipMemcpyHostToDevice));
     for (int g = 0; g < S->ng; ++g) {
         const double *src = (to_device ? tmp : dev) + (size_t)g * S->nphi;
@@ -1078,7 +1080,6 @@ static int phi_transfer(nf_solver *S, double *host, bool to_device, double *dev 
     }
     HIPCHK(hipStreamSynchronize(st));
     if (!to_device) HIPCHK(hipMemcpy(host, tmp, NN * sizeof(double), hipMemcpyDeviceToHost));
-    dfree(tmp);
     return NF_OK;
 }
 int nf_set_phi(nf_handle S, const double *phi)
@@ -1143,7 +1144,7 @@ int nf_get_J(nf_handle S, double *J_host)
         if (S->k != 0) return fail(NF_ERR_UNSUPPORTED, "nf_get_J on a slab is implemented for RT0 only");
         NFCHK(team_reconstruct_Jz(S->team));
     }
-    double *dJ = nullptr; NFCHK(dalloc(&dJ, (size_t)nJ));
+    DevTmp<double> dJ_; NFCHK(dalloc(&dJ_.p, (size_t)nJ)); double *dJ = dJ_.p;
     Geom G = make_geom(S);
     int nfa = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nfa *= S->k + 1; ni *= S->k + 1; }
     const long nJface = S->nJx + S->nJy + S->nJz;
@@ -1164,7 +1165,6 @@ int nf_get_J(nf_handle S, double *J_host)
         HIPCHK(hipMemcpyAsync(J_host + (size_t)g * nJ, dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    dfree(dJ);
     HIPCHK(hipGetLastError());
     return NF_OK;
 }
@@ -1616,7 +1616,7 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
     if (use_direct_keff && T->has_valid_keff) keff = T->last_keff;          // :1885-1889
     if (!S->d_phi_adj) NFCHK(dalloc(&S->d_phi_adj, (size_t)NT));
     hipLaunchKernelGGL(k_fill_const, dim3(GT), dim3(256), 0, st, S->d_phi_adj, NT, 1.0 / std::sqrt((double)NT));   // 1 / ||1||  (:1891-1892)
-    double *d_nsft = nullptr; NFCHK(dalloc(&d_nsft, (size_t)N));
+    DevTmp<double> nsft_; NFCHK(dalloc(&nsft_.p, (size_t)N)); double *d_nsft = nsft_.p;
     hipLaunchKernelGGL(k_sum_groups, dim3(grid_for(N)), dim3(256), 0, st, S->d_NSF, d_nsft, N, ng);                  // :1898-1905
     const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || NP < 200;
     const double cg_tol = direct ? 1e-14 : o->tol_flux;
@@ -1694,7 +1694,6 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
         dfree(d_mass); dfree(d_one);
     }
     (void)hipStreamSynchronize(st);
-    dfree(d_nsft);
     if (rc != NF_OK) return rc;
     HIPCHK(hipGetLastError());
     S->raw_valid = false;
