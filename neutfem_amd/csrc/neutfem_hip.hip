@@ -39,7 +39,20 @@ static int fail(int code, const char *fmt, ...)
 static const int RED_GRID = 1024;          // fixed grid of the streaming/reduction kernels
 static const int MAX_LOCAL_SLABS = 16;
 
-struct ProfSlot { long count = 0; double ms = 0.0; double max_ms = 0.0; long skipped = 0; };
+// event-timed launches of one pass.  Launches queued behind a converged CG solve exit at once (CgScalars::done): they are no
+// work and must not dilute the average, and an occasional preempted launch must not distort it either, so the figures are
+// taken over the samples of at least a quarter of the MEDIAN duration.
+struct ProfSlot {
+    std::vector<float> samples;
+    void stats(long *count, double *ms, long *skipped) const
+    {
+        *count = 0; *ms = 0.0; *skipped = 0;
+        if (samples.empty()) return;
+        std::vector<float> v(samples); std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+        const double thr = 0.25 * v[v.size() / 2];
+        for (float x : samples) { if (x < thr) ++*skipped; else { ++*count; *ms += x; } }
+    }
+};
 
 // ---- RCCL, resolved lazily with dlopen so that single-GPU use never loads it -------------------
 typedef struct ncclComm *ncclComm_t;
@@ -612,22 +625,12 @@ static void prof_begin(nf_team *T, int slot, hipEvent_t *a, hipEvent_t *b)
     (void)hipEventRecord(*a, T->stream);
     T->ev_pending.push_back({*a, *b, slot});
 }
-// Launches queued behind a converged CG solve exit at once (CgScalars::done); they are no work and must not dilute the
-// average duration of a pass: samples shorter than a quarter of the slot's longest one are counted apart (`skipped`).
 static void prof_collect(nf_team *T)
 {
-    std::vector<std::pair<int, float>> got;
     for (auto &e : T->ev_pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            got.push_back({e.slot, ms});
-            auto &sl = T->prof[SLOT_NAMES[e.slot]]; if (ms > sl.max_ms) sl.max_ms = ms;
-        }
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) T->prof[SLOT_NAMES[e.slot]].samples.push_back(ms);
         T->ev_free.push_back({e.a, e.b});
-    }
-    for (auto &g : got) {
-        auto &sl = T->prof[SLOT_NAMES[g.first]];
-        if (g.second < 0.25 * sl.max_ms) sl.skipped += 1; else { sl.count += 1; sl.ms += g.second; }
     }
     T->ev_pending.clear();
 }
@@ -1409,8 +1412,9 @@ int nf_timers(nf_handle S, char *buf, size_t len)
     std::string js = "{";
     char tmp[160];
     for (const char *nm : SLOT_NAMES) {
-        const ProfSlot &sl = T->prof[nm];
-        snprintf(tmp, sizeof tmp, "\"%s\": {\"count\": %ld, \"ms\": %.6f, \"skipped_noop\": %ld}, ", nm, sl.count, sl.ms, sl.skipped);
+        long c = 0, sk = 0; double msum = 0.0;
+        T->prof[nm].stats(&c, &msum, &sk);
+        snprintf(tmp, sizeof tmp, "\"%s\": {\"count\": %ld, \"ms\": %.6f, \"skipped_noop\": %ld}, ", nm, c, msum, sk);
         js += tmp;
     }
     snprintf(tmp, sizeof tmp, "\"last_outer\": %d, \"coarse_outer\": %d, \"last_cg_total\": %ld, \"separator_sweeps\": %d}", T->last_outer, T->coarse_outer, T->last_cg_total, T->sep_sweeps);
@@ -1727,8 +1731,10 @@ int nf_profile_get(nf_handle S, const char *name, long *count, double *total_ms)
 {
     if (!S || !name) return fail(NF_ERR_ARG, "nf_profile_get: bad arguments");
     auto it = S->team->prof.find(name);
-    if (count) *count = it == S->team->prof.end() ? 0 : it->second.count;
-    if (total_ms) *total_ms = it == S->team->prof.end() ? 0.0 : it->second.ms;
+    long c = 0, sk = 0; double ms = 0.0;
+    if (it != S->team->prof.end()) it->second.stats(&c, &ms, &sk);
+    if (count) *count = c;
+    if (total_ms) *total_ms = ms;
     return NF_OK;
 }
 int nf_profile_reset(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->team->prof.clear(); return NF_OK; }

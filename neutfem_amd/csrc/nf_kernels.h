@@ -664,12 +664,11 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     }
     double dinv_s = 0.0;
     if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
-    double t[SEG];
+    double t[NB > 0 ? SEG : 1];                                  // NB == 0: t_i = xv_i - xv_{i+1} is recomputed where needed (registers)
     double P = 1.0, lz = 0.0;
     double xL0 = xv[0];                                          // xL of this segment's first cell
     if (NB == 0) {
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) t[i] = xv[i] - xv[i + 1];
+        (void)t;
     } else {
         double xLc[SEG + 1], xRc[SEG];
 #pragma unroll
@@ -683,7 +682,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
         for (int i = 0; i < SEG; ++i) t[i] = xRc[i] - xLc[i + 1];
     }
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { lz = t[i] - Lv[i] * lz; P = -Lv[i] * P; }
+    for (int i = 0; i < SEG; ++i) { const double ti = NB == 0 ? xv[i] - xv[i + 1] : t[NB > 0 ? i : 0]; lz = ti - Lv[i] * lz; P = -Lv[i] * P; }
     sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz;
     if (seg == 0) sZ0[ixl] = x_before - xL0;
     __syncthreads();
@@ -697,7 +696,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     const double zin = z;
     double w[SEG];
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { z = t[i] - Lv[i] * z; w[i] = z * Rv[i]; }
+    for (int i = 0; i < SEG; ++i) { const double ti = NB == 0 ? xv[i] - xv[i + 1] : t[NB > 0 ? i : 0]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; }
     double Q = 1.0, lu = 0.0;
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
@@ -742,17 +741,21 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
             for (int i = 0; i < SEG; ++i) if (c0 + i < n) sa.jz[(long)(fs + c0 + i + 1) * nxy + lineid] = -w[i];
             if (seg == 0) {
                 sa.jz[(long)fs * nxy + lineid] = -ulo;           // lower face of the first chain cell
-                if (sa.if_lo) sa.jz[lineid] = -u_lo;             // the separators themselves
-                if (sa.if_hi) sa.jz[(long)(fs + n + 1) * nxy + lineid] = -u_hi;
+                if (sa.if_lo) sa.jz[lineid] = -sa.ulo[lm];       // the separators themselves
+                if (sa.if_hi) sa.jz[(long)(fs + n + 1) * nxy + lineid] = -sa.uhi[lm];
             }
         }
         return;
     }
     if (SLAB) {
         // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1
+        // (edge values are re-read here instead of being kept live across the two scans: x holds the updated p by now, and the
+        // per-line coefficients come from L2 -- the kernel sits at the 128-VGPR limit of a 1024-thread block)
         if (valid && seg == 0 && sa.if_lo) {
-            if (sa.mode == 1) sa.clo[lm] = -xe_lo - a_lo * ulo;
+            const double a_lo = sa.alo[lineid];
+            if (sa.mode == 1) sa.clo[lm] = -(NB == 0 ? x[edge_lo] : xe_lo) - a_lo * ulo;
             else {
+                const double u_lo = sa.ulo[lm];
                 const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv;
                 if (NB > 0) {                                    // bubbles of the edge cell: faces (separator, first chain face)
                     const double ice = ma.D[edge_lo] / geom_factor(G, DIR, ix, (int)by, 0);
@@ -770,8 +773,10 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
             double ulast = 0.0;
 #pragma unroll
             for (int i = 0; i < SEG; ++i) if (c0 + i == n - 1) ulast = w[i];
-            if (sa.mode == 1) sa.chi[lm] = xe_hi - a_hi * ulast;
+            const double a_hi = sa.ahi[lineid];
+            if (sa.mode == 1) sa.chi[lm] = (NB == 0 ? x[edge_hi] : xe_hi) - a_hi * ulast;
             else {
+                const double u_hi = sa.uhi[lm];
                 const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv;
                 if (NB > 0) {                                    // faces (last chain face, separator)
                     const int fsz = sa.if_lo ? 1 : 0;
