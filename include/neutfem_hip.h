@@ -48,7 +48,7 @@ int nf_destroy(nf_handle h);
  * by the launcher (torch.distributed / MPI / a file), every rank calls nf_comm_init.  Rank r must hold the slabs
  * just above rank r-1's.  After that nf_solve_keff / nf_time_schur_apply on any slab of the team run the whole
  * team; nf_set_phi / nf_get_phi / nf_upload_xs / nf_build stay per slab.
- * Collective calls (every rank, same order): nf_comm_init, nf_solve_keff, nf_build_diagonal_cache,
+ * Collective calls (every rank, same order): nf_comm_init, nf_solve_keff, nf_solve_adjoint, nf_get_J, nf_build_diagonal_cache,
  * nf_team_schur_apply, nf_time_schur_apply.  Decisions that could differ between ranks (slab too thin for the
  * separator sweeps, coarse factors that do not divide a slab) are all-reduced first, so all ranks return the same
  * error.  Any RTk-Pm order; slabs need >= 4 z-planes (>= ~30 for the single-exchange fast path).

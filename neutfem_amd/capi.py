@@ -361,6 +361,12 @@ class HipTeam:
     def reset_flux(self):
         for s in self.slabs: s.reset_flux()
 
+    def solve_adjoint(self, normalize_to_direct=True, use_direct_keff=True):
+        return self.head.solve_adjoint(normalize_to_direct, use_direct_keff)
+
+    def get_phi_adj_local(self):
+        return np.concatenate([s.get_phi_adj().reshape(self.ng, s.nz, s.ny, s.nx) for s in self.slabs], axis=1)
+
     def history(self): return self.head.history()
     def profile(self, name): return self.head.profile(name)
     def profile_reset(self): self.head.profile_reset()

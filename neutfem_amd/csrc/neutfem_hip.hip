@@ -270,7 +270,7 @@ static int team_alloc(nf_team *T)
     T->slab_cap = cap; T->partial_stride = cap * (long)T->slabs.size();
     NFCHK(dalloc(&T->d_partials, (size_t)T->partial_stride * 4));
     if (!T->d_cg) NFCHK(dalloc(&T->d_cg, 1));
-    if (!T->d_out) NFCHK(dalloc(&T->d_out, 4));
+    if (!T->d_out) NFCHK(dalloc(&T->d_out, 8));
     if (!T->d_red) NFCHK(dalloc(&T->d_red, 4));
     T->last_its.assign(64, 0);
     return NF_OK;
@@ -1605,26 +1605,44 @@ int nf_solve_keff(nf_handle S, const nf_keff_opts *o, double *keff, int *n_outer
 
 // ---- SolveAdjoint (src/NeutFEM.cpp:1877-2082) -----------------------------------------------------
 // Literal control flow of the reference, including what makes it fragile (forward-ordered sweep on the transposed scatter,
-// Chebyshev from outer 5 when k is free).  Undivided meshes only.
+// Chebyshev from outer 5 when k is free).  Works on slab teams (collective).
 int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct, int use_direct_keff, double *keff_adj, int *n_outer)
 {
     if (!S || !o) return fail(NF_ERR_ARG, "nf_solve_adjoint: bad arguments");
-    if (!S->built) return fail(NF_ERR_STATE, "nf_solve_adjoint: call nf_build first");
     nf_team *T = S->team;
-    if (!team_is_single(T)) return fail(NF_ERR_UNSUPPORTED, "the adjoint solve is not available on a slab-decomposed mesh");
-    HIPCHK(hipSetDevice(S->device));
-    const int ng = S->ng; const long N = S->N, NP = S->nphi, NT = NP * ng;
-    const int G = grid_for(NP), GT = grid_for(NT);
+    for (auto *X : T->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_solve_adjoint: call nf_build first");
+    HIPCHK(hipSetDevice(T->device));
+    NFCHK(team_prepare(T));
+    const int ns = (int)T->slabs.size();
+    nf_solver *S0 = T->slabs[0];
+    const int ng = S0->ng;
     hipStream_t st = T->stream;
     double keff = 1.0;
     if (use_direct_keff && T->has_valid_keff) keff = T->last_keff;          // :1885-1889
-    if (!S->d_phi_adj) NFCHK(dalloc(&S->d_phi_adj, (size_t)NT));
-    hipLaunchKernelGGL(k_fill_const, dim3(GT), dim3(256), 0, st, S->d_phi_adj, NT, 1.0 / std::sqrt((double)NT));   // 1 / ||1||  (:1891-1892)
-    DevTmp<double> nsft_; NFCHK(dalloc(&nsft_.p, (size_t)N)); double *d_nsft = nsft_.p;
-    hipLaunchKernelGGL(k_sum_groups, dim3(grid_for(N)), dim3(256), 0, st, S->d_NSF, d_nsft, N, ng);                  // :1898-1905
-    const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || NP < 200;
+    // global number of flux DOFs (the start vector is 1 / ||1||, :1891-1892): local sum, all-reduced on a multi-rank team
+    double ntot = 0.0; long NPtot = 0;
+    for (auto *X : T->slabs) { ntot += (double)X->nphi * ng; NPtot += X->nphi; }
+    if (T->rccl_reduce && T->nproc > 1) {
+        HIPCHK(hipMemcpyAsync(T->d_red, &ntot, sizeof(double), hipMemcpyHostToDevice, st));
+        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_SUM, T->comm, st));
+        HIPCHK(hipMemcpyAsync(&ntot, T->d_red, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    std::vector<DevTmp<double>> nsft(ns);
+    std::vector<int> gN(ns), gT(ns);
+    std::vector<const double *> rhs(ns); std::vector<double *> sol(ns);
+    for (int i = 0; i < ns; ++i) {
+        nf_solver *X = T->slabs[i];
+        const long NT = X->nphi * ng;
+        gN[i] = grid_for(X->nphi); gT[i] = grid_for(NT);
+        if (!X->d_phi_adj) NFCHK(dalloc(&X->d_phi_adj, (size_t)NT));
+        hipLaunchKernelGGL(k_fill_const, dim3(gT[i]), dim3(256), 0, st, X->d_phi_adj, NT, 1.0 / std::sqrt(ntot));
+        NFCHK(dalloc(&nsft[i].p, (size_t)X->N));
+        hipLaunchKernelGGL(k_sum_groups, dim3(grid_for(X->N)), dim3(256), 0, st, X->d_NSF, nsft[i].p, X->N, ng);    // :1898-1905
+    }
+    const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (team_is_single(T) && NPtot < 200);
     const double cg_tol = direct ? 1e-14 : o->tol_flux;
-    const int cg_max = direct ? (int)std::min<long>(20 * NP + 50, 2000000000L) : o->max_inner;
+    const int cg_max = direct ? (int)std::min<long>(20 * NPtot + 50, 2000000000L) : o->max_inner;
     const int nmax = 15; const double sigma = 0.98;
     double ca[16], cbv[16];
     { const double Gm = std::acosh(2. / sigma - 1.); ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
@@ -1634,30 +1652,44 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
     T->last_outer = 0; T->last_cg_total = 0;
     ScatterArgs sa; sa.ng = ng;
     double hout[4];
-    const std::vector<int> cG = { G }, cGT = { GT };
     int rc = NF_OK;
+    // sum_e nsf_tot[e] * (M_chi v)[e, dof 0] over the team, result in `out` (:1912-1936)
+    auto chi_product = [&](bool of_raw, double *out) -> int {
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *X = T->slabs[i];
+            hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, st, X->d_Mchi, of_raw ? X->d_raw : X->d_phi_adj, ng, X->nphi, X->d_tf,
+                               T->d_partials + i * T->slab_cap, (const double *)nsft[i].p, X->N);
+        }
+        return team_finalize(T, FIN_SUM, gN, 1, out, 0.0, 0);
+    };
     for (int it = 0; it < o->max_outer && rc == NF_OK; ++it) {
-        // total_chi_adj and prod_old = sum_e nsf_tot[e] * tca[e, dof 0]   (:1912-1936)
-        hipLaunchKernelGGL(k_fission, dim3(G), dim3(256), 0, st, S->d_Mchi, S->d_phi_adj, ng, NP, S->d_tf, T->d_partials, (const double *)d_nsft, N);
-        if ((rc = team_finalize(T, FIN_SUM, cG, 1, T->d_out, 0.0, 0)) != NF_OK) break;
+        if ((rc = chi_product(false, T->d_out)) != NF_OK) break;
         for (int g = 0; g < ng && rc == NF_OK; ++g) {
-            for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[gp * ng + g] : nullptr;           // transposed blocks (:1944-1950)
-            hipLaunchKernelGGL(k_group_rhs, dim3(G), dim3(256), 0, st, sa, g, S->d_NSF + g * N, S->d_tf, 1.0 / keff, S->d_raw, S->d_phi_adj,
-                               (const double *)nullptr, S->d_rhs, NP, N);
+            for (int i = 0; i < ns; ++i) {
+                nf_solver *X = T->slabs[i];
+                for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? X->d_Ms[gp * ng + g] : nullptr;       // transposed blocks (:1944-1950)
+                hipLaunchKernelGGL(k_group_rhs, dim3(gN[i]), dim3(256), 0, st, sa, g, X->d_NSF + g * X->N, X->d_tf, 1.0 / keff, X->d_raw, X->d_phi_adj,
+                                   (const double *)nullptr, X->d_rhs, X->nphi, X->N);
+                rhs[i] = X->d_rhs; sol[i] = X->d_raw + g * X->nphi;
+            }
             int its = 0;
-            rc = cg_solve(T, g, { S->d_rhs }, { S->d_raw + g * NP }, cg_tol, cg_max, &its, nullptr);
+            rc = cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr);
             T->hist_cg.push_back(its); T->last_cg_total += its;
         }
         if (rc != NF_OK) break;
-        hipLaunchKernelGGL(k_fission, dim3(G), dim3(256), 0, st, S->d_Mchi, S->d_raw, ng, NP, S->d_tf, T->d_partials, (const double *)d_nsft, N);
-        if ((rc = team_finalize(T, FIN_SUM, cG, 1, T->d_out + 1, 0.0, 0)) != NF_OK) break;
-        hipLaunchKernelGGL(k_outer_reduce, dim3(GT), dim3(256), 0, st, S->d_Mchi, S->d_raw, S->d_phi_adj, NT, T->d_partials, T->partial_stride);
-        if ((rc = team_finalize(T, FIN_SUM, cGT, 3, T->d_red, 0.0, 0)) != NF_OK) break;        // d_red: { unused, ||phi||^2, ||dphi||^2 }
-        double hred[3];
-        if (hipMemcpyAsync(hout, T->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(hred, T->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { rc = fail(NF_ERR_HIP, "adjoint: read-back failed"); break; }
-        const double prod_old = hout[0], prod_new = hout[1], nsq = hred[1], dsq = hred[2];
+        // NB: chi_product(true) overwrites d_tf with M_chi raw; the next outer recomputes it from phi_adj first
+        if ((rc = chi_product(true, T->d_out + 1)) != NF_OK) break;
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *X = T->slabs[i];
+            hipLaunchKernelGGL(k_outer_reduce, dim3(gT[i]), dim3(256), 0, st, X->d_Mchi, X->d_raw, X->d_phi_adj, X->nphi * ng, T->d_partials + i * T->slab_cap, T->partial_stride);
+        }
+        if ((rc = team_finalize(T, FIN_SUM, gT, 3, T->d_out + 2, 0.0, 0)) != NF_OK) break;     // d_out[2..4]: { unused, ||phi||^2, ||dphi||^2 }
+        double h5[5];
+        if (hipMemcpyAsync(h5, T->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = fail(NF_ERR_HIP, "adjoint: read-back failed"); break;
+        }
+        hout[0] = h5[0]; hout[1] = h5[1];
+        const double prod_old = hout[0], prod_new = hout[1], nsq = h5[3], dsq = h5[4];
         double keff_new = keff, dk;
         if (!use_direct_keff || !T->has_valid_keff) {                          // :1966-1975
             if (std::fabs(prod_old) > 1e-14 && it > 0) keff_new = keff * (prod_new / prod_old);
@@ -1669,11 +1701,15 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
         if (!use_direct_keff && it >= 5) {                                     // :1990-1992
             if (cheb_it == nmax) cheb_it = 0;
             if (cheb_it == 0) mode = 1; else if (cheb_it == 1) { mode = 2; a = ca[1]; } else { mode = 3; a = (4. / sigma) * ca[cheb_it]; b = cbv[cheb_it]; }
-            if (!S->d_p0) { if ((rc = dalloc(&S->d_p0, (size_t)NT)) != NF_OK || (rc = dalloc(&S->d_p1, (size_t)NT)) != NF_OK) break; }
             ++cheb_it;
         }
-        hipLaunchKernelGGL(k_normalize_cheb, dim3(GT), dim3(256), 0, st, S->d_raw, S->d_phi_adj, S->d_p0, S->d_p1, NT, norm, norm > 1e-14 ? 1 : 0, mode, a, b);
-        if (mode == 3) std::swap(S->d_p0, S->d_p1);
+        for (int i = 0; i < ns && rc == NF_OK; ++i) {
+            nf_solver *X = T->slabs[i]; const long NT = X->nphi * ng;
+            if (mode && !X->d_p0) { if ((rc = dalloc(&X->d_p0, (size_t)NT)) != NF_OK || (rc = dalloc(&X->d_p1, (size_t)NT)) != NF_OK) break; }
+            hipLaunchKernelGGL(k_normalize_cheb, dim3(gT[i]), dim3(256), 0, st, X->d_raw, X->d_phi_adj, X->d_p0, X->d_p1, NT, norm, norm > 1e-14 ? 1 : 0, mode, a, b);
+            if (mode == 3) std::swap(X->d_p0, X->d_p1);
+        }
+        if (rc != NF_OK) break;
         T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
         T->last_outer = it + 1;
         bool conv = dphi < o->tol_flux;
@@ -1681,27 +1717,29 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
         if (conv) break;
     }
     if (rc == NF_OK && normalize_to_direct && T->has_valid_keff) {            // <phi, phi+> = 1 with vol * w = detJ * C-hat_pp (:2020-2066)
-        double *d_mass = nullptr, *d_one = nullptr;
-        rc = dalloc(&d_mass, (size_t)NP); if (rc == NF_OK) rc = dalloc(&d_one, (size_t)N);
-        if (rc == NF_OK) {
-            ChatArgs ch; ch.nloc = S->nloc;
-            for (int p = 0; p < S->nloc; ++p) { int q = p; double c = 1.0; for (int t = 0; t < S->dim; ++t) { c *= 2.0 / (2.0 * (q % S->n1) + 1.0); q /= S->n1; } ch.c[p] = c; }
-            hipLaunchKernelGGL(k_fill_const, dim3(grid_for(N)), dim3(256), 0, st, d_one, N, 1.0);
-            hipLaunchKernelGGL(k_cell_coef, dim3(grid_for(N, 256, 65535)), dim3(256), 0, st, d_one, d_mass, S->d_hx, S->d_hy, S->d_hz, S->nx, S->ny, N, 2, S->dim, ch);
-            hipLaunchKernelGGL(k_dot3, dim3(GT), dim3(256), 0, st, S->d_phi, S->d_phi_adj, d_mass, NP, ng, T->d_partials);
-            rc = team_finalize(T, FIN_SUM, cGT, 1, T->d_out, 0.0, 0);
-            double ip = 0.0;
-            if (rc == NF_OK && (hipMemcpyAsync(&ip, T->d_out, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-                rc = fail(NF_ERR_HIP, "adjoint: read-back failed");
-            if (rc == NF_OK && std::fabs(ip) > 1e-14) hipLaunchKernelGGL(k_scale, dim3(GT), dim3(256), 0, st, S->d_phi_adj, NT, ip);
+        std::vector<DevTmp<double>> mass(ns), one(ns);
+        for (int i = 0; i < ns && rc == NF_OK; ++i) {
+            nf_solver *X = T->slabs[i];
+            rc = dalloc(&mass[i].p, (size_t)X->nphi); if (rc == NF_OK) rc = dalloc(&one[i].p, (size_t)X->N);
+            if (rc != NF_OK) break;
+            ChatArgs ch; ch.nloc = X->nloc;
+            for (int p = 0; p < X->nloc; ++p) { int q = p; double c = 1.0; for (int t = 0; t < X->dim; ++t) { c *= 2.0 / (2.0 * (q % X->n1) + 1.0); q /= X->n1; } ch.c[p] = c; }
+            hipLaunchKernelGGL(k_fill_const, dim3(grid_for(X->N)), dim3(256), 0, st, one[i].p, X->N, 1.0);
+            hipLaunchKernelGGL(k_cell_coef, dim3(grid_for(X->N, 256, 65535)), dim3(256), 0, st, one[i].p, mass[i].p, X->d_hx, X->d_hy, X->d_hz, X->nx, X->ny, X->N, 2, X->dim, ch);
+            hipLaunchKernelGGL(k_dot3, dim3(gT[i]), dim3(256), 0, st, X->d_phi, X->d_phi_adj, mass[i].p, X->nphi, ng, T->d_partials + i * T->slab_cap);
         }
-        dfree(d_mass); dfree(d_one);
+        if (rc == NF_OK) rc = team_finalize(T, FIN_SUM, gT, 1, T->d_out, 0.0, 0);
+        double ip = 0.0;
+        if (rc == NF_OK && (hipMemcpyAsync(&ip, T->d_out, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+            rc = fail(NF_ERR_HIP, "adjoint: read-back failed");
+        if (rc == NF_OK && std::fabs(ip) > 1e-14)
+            for (int i = 0; i < ns; ++i) hipLaunchKernelGGL(k_scale, dim3(gT[i]), dim3(256), 0, st, T->slabs[i]->d_phi_adj, T->slabs[i]->nphi * ng, ip);
+        (void)hipStreamSynchronize(st);
     }
     (void)hipStreamSynchronize(st);
     if (rc != NF_OK) return rc;
     HIPCHK(hipGetLastError());
-    S->raw_valid = false;
-    S->has_valid_adjoint = 1; S->last_keff_adj = keff;
+    for (auto *X : T->slabs) { X->raw_valid = false; X->has_valid_adjoint = 1; X->last_keff_adj = keff; }
     if (keff_adj) *keff_adj = keff;
     if (n_outer) *n_outer = T->last_outer;
     return NF_OK;

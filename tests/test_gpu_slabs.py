@@ -214,3 +214,24 @@ def test_team_higher_orders_match_oracle(shape, planes, rt, p):
     phi = np.concatenate([s.get_phi().reshape(2, -1) for s in t.slabs], axis=1)
     assert rel_l2(phi.ravel(), o.phi_dofs().ravel()) < 1e-8
     t.close()
+
+
+@pytest.mark.parametrize("planes", [[(0, 20), (20, 40)], [(0, 10), (10, 22), (22, 40)]])
+def test_team_adjoint_matches_undivided_and_oracle(planes):
+    """SolveAdjoint (src/NeutFEM.cpp:1877-2082) on a slab team: fixed-k mode to convergence, bi-orthonormalised against the
+    team's direct flux; and the first free-k outers (before the reference's Chebyshev step destabilises them)"""
+    inp = synthetic_inputs(8, 7, 40, 2, seed=23, dirichlet=(1, 2, 4, 5, 6))
+    o, s, t = make_oracle(inp), make_hip(inp), make_team(inp, planes)
+    tol = (1e-10, 1e-9, 1e-9, 400, 3000)
+    o.set_tol(*tol); s.set_tol(*tol); t.set_tol(*tol)
+    ko = o.SolveKeff(); ks, _ = s.solve_keff(); kt, _ = t.solve_keff()
+    for x in (o, s, t): x.set_tol(1e-10, 1e-9, 1e-9, 30, 3000)        # fixed work: 30 adjoint outers
+    ka_o = o.SolveAdjoint(True, True); ka_s, na_s = s.solve_adjoint(True, True); ka_t, na_t = t.solve_adjoint(True, True)
+    assert ka_t == kt and abs(ka_t - ka_o) / ka_o < 1e-9 and na_t == na_s == 30
+    pa = t.get_phi_adj_local().ravel()
+    assert rel_l2(pa, s.get_phi_adj().ravel()) < 1e-6 and rel_l2(pa, o.phi_adj_dofs().ravel()) < 1e-6
+    o.set_tol(1e-10, 1e-9, 1e-9, 5, 3000); t.set_tol(1e-10, 1e-9, 1e-9, 5, 3000)
+    kf_o = o.SolveAdjoint(False, False); kf_t, n = t.solve_adjoint(False, False)
+    assert n == 5 and abs(kf_t - kf_o) / kf_o < 1e-8
+    assert rel_l2(t.get_phi_adj_local().ravel(), o.phi_adj_dofs().ravel()) < 1e-6
+    s.close(); t.close()
