@@ -117,7 +117,7 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
-    int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1;
+    int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID;
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
@@ -157,6 +157,7 @@ struct nf_solver {
     double *d_tf = nullptr, *d_rhs = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
     bool raw_valid = false, raw_is_diag = false;
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
+    CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
     double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nx*ny*(nz+1) (nf_get_J)
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
     bool cmfd_init = false; double cmfd_relax = 1.0;
@@ -757,8 +758,8 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const CgFuse fz = (S->if_lo || S->if_hi) ? CgFuse{ nullptr, nullptr, nullptr } : S->fuse;   // slabs fuse in their endpoint pass instead
     const ModeTab mt = mode_tab(S, 0);
     const dim3 gr(grid, (unsigned)mt.n);                          // all transverse modes in one launch
-    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
-    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz);
+    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
+    else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
 }
 template <int NB>
 static int launch_x_nb(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts)
@@ -962,18 +963,31 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     // (undivided mesh: in the x pass; slab teams: in the endpoint pass of the z lines, the first pass to read p)
     const bool fused = T->opt_fuse != 0 && (team_is_single(T) || T->slabs[0]->nloc == 1);   // undivided: any order (x pass); slab teams: P0 (z endpoint pass)
     for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
+    // lean variant on top of the fused one (undivided mesh, no RCCL): no k_finalize launches, see CgLean.  Row 0 of the partial
+    // buffer holds the p.q partials of the last direction pass, row 1 the |r|^2 partials of k_cg_rupdate.
+    const bool lean = fused && T->opt_lean && team_is_single(T) && !T->rccl_reduce;
+    // every block of the next x pass sums the |r|^2 partials; fewer partials (cg_lean_grid) cost k_cg_rupdate more than they save (measured)
+    const int gru = lean ? grid_for(T->slabs[0]->nphi, 256, T->opt_lean_grid) : 0;
+    double *row1 = T->d_partials + T->partial_stride;
+    const CgLean no_lean = { nullptr, nullptr, 0, 0, 0 };
     int rc = NF_OK;
     while (launched < maxit && rc == NF_OK) {
         int nb = std::min(batch, maxit - launched);
         for (int it = 0; it < nb && rc == NF_OK; ++it) {
+            const int index = launched + it;                      // iteration number within this solve
+            if (lean) T->slabs[0]->lean = CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 };
             rc = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
-            if (rc == NF_OK) rc = team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0);
+            if (lean) T->slabs[0]->lean = no_lean;
+            if (rc == NF_OK && !lean) rc = team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0);
             if (rc != NF_OK) break;
             for (int i = 0; i < ns; ++i) {
                 nf_solver *S = T->slabs[i];
-                if (fused) hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
+                if (lean) hipLaunchKernelGGL(k_cg_rupdate, dim3(gru), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, row1,
+                                             CgLean{ T->d_cg, T->d_partials, acnt[0], index & 1, 0 });
+                else if (fused) hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap, no_lean);
                 else hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
             }
+            if (lean) continue;
             rc = team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0);
             if (fused) continue;
             for (int i = 0; i < ns; ++i) {
@@ -983,6 +997,8 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         }
         if (rc != NF_OK) break;
         launched += nb;
+        // lean: the stop tests of the batch's last iteration have not been evaluated yet (the next x pass would do it)
+        if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 });
         if (hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream) != hipSuccess || hipStreamSynchronize(T->stream) != hipSuccess) {
             rc = fail(NF_ERR_HIP, "CG: reading the device scalars failed"); break;
         }
@@ -1850,6 +1866,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
     else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
+    else if (!strcmp(key, "cg_lean")) T->opt_lean = value != 0;
+    else if (!strcmp(key, "cg_lean_grid")) T->opt_lean_grid = (int)std::max(1L, std::min(1024L, value));
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
 }

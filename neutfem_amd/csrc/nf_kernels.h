@@ -21,6 +21,9 @@ struct CgScalars {
     double rr, pAp, alpha, beta, rr_new, tol_sq, rhs_norm, tol;
     int done, its, maxit;
     int pend;      // fused CG only: the x += alpha p of the last FIN_RR has not been applied yet (k_schur_x / k_cg_flush do it)
+    // lean CG (CgLean): |r|^2 and the iteration count after the iteration of parity q, so that a kernel whose blocks all read
+    // the values of parity q^1 can have its block 0 store those of parity q without a race
+    double rr2[2]; int its2[2];
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -58,6 +61,7 @@ __device__ __forceinline__ void cg_logic(int op, const double *tot, int nq, CgSc
         cg->tol = tol;
         cg->tol_sq = tol * tol * cg->rhs_norm * cg->rhs_norm;
         cg->done = 0; cg->its = 0; cg->maxit = maxit; cg->pend = 0;
+        cg->rr2[0] = tot[0]; cg->its2[0] = 0;
         if (maxit <= 0) cg->done = 1;
     } else if (op == FIN_PAP) {                // src/solvers.cpp:602-606
         cg->pAp = tot[0];
@@ -108,6 +112,55 @@ __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgSca
     double tot[4] = { 0, 0, 0, 0 };
     for (int q = 0; q < nq; ++q) tot[q] = red[q];
     cg_logic(op, tot, nq, cg, out, tol, maxit);
+}
+
+// Lean CG (undivided mesh, fused): the two k_finalize launches of an iteration disappear.  The consumer of a reduction sums
+// the producer's block partials itself -- every block redundantly, in k_finalize's order, so all blocks get the same bits --
+// and its block 0 stores the scalars for the kernels (and the host) that follow:
+//   k_cg_rupdate sums the p.q partials of the last direction pass  -> alpha            (FIN_PAP, src/solvers.cpp:602-606)
+//   the next iteration's x pass sums the |r|^2 partials of k_cg_rupdate -> beta, stop tests  (FIN_RR, :613-631)
+// No block reads a field that another block of the same kernel writes: |r|^2 and the iteration count are kept per parity of
+// the iteration (CgScalars::rr2 / its2); `done` is sticky and every block derives the same stop decision on its own.
+// k_cg_lean_rr applies the FIN_RR step alone (idempotent: same inputs, same parity slot) so that the host, which reads the
+// scalars at the end of a batch, sees the outcome of the batch's last iteration.
+struct CgLean { CgScalars *st; const double *partials; int count; int par; int first; };
+__device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred)   // 256-thread blocks; result in every thread
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 256) s += p[i];
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) sred[0] = s;
+    __syncthreads();
+    s = sred[0];
+    __syncthreads();
+    return s;
+}
+// FIN_RR for the iteration of parity lean.par; returns true when the solve stops here.  *beta_out is valid when it continues.
+__device__ __forceinline__ bool lean_rr_step(const CgLean &lean, bool writer, double *sred, double *beta_out)
+{
+    CgScalars *st = lean.st;
+    const int q = lean.par, qo = q ^ 1;
+    const double rr_new = strided_total(lean.partials, lean.count, sred);
+    const double rr_old = st->rr2[qo];
+    const int its_new = st->its2[qo] + 1;
+    const bool conv = rr_new < st->tol_sq;
+    const bool stop = conv || its_new >= st->maxit;
+    const double beta = rr_new / rr_old;
+    if (writer) {
+        st->rr2[q] = rr_new; st->its2[q] = its_new;
+        st->rr_new = rr_new; st->rr = rr_new; st->its = its_new; st->pend = 1;
+        if (!conv) st->beta = beta;
+        if (stop) st->done = 1;
+    }
+    *beta_out = beta;
+    return stop;
+}
+__global__ __launch_bounds__(256) void k_cg_lean_rr(CgLean lean)
+{
+    __shared__ double sred[4];
+    if (lean.st->done) return;
+    double beta;
+    (void)lean_rr_step(lean, threadIdx.x == 0, sred, &beta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,11 +458,16 @@ template <int K, int NCH, bool VEC, int NB>
 __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                                                  const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
                                                  int first, int last, double *__restrict__ partials,
-                                                 const CgScalars *__restrict__ cg, CgFuse fz)
+                                                 const CgScalars *__restrict__ cg, CgFuse fz, CgLean lean)
 {
     static_assert(K == 2, "two cells per lane and chunk");
     __shared__ double sred[4];
     if (cg && cg->done) return;
+    bool lean_fuse = false; double lean_beta = 0.0;
+    if (lean.st && !lean.first) {                               // lean CG: this pass consumes the |r|^2 partials (FIN_RR)
+        if (lean_rr_step(lean, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &lean_beta)) return;
+        lean_fuse = true;
+    }
     const ModeArgs ma = select_mode(ma0, mt, blockIdx.y, NB + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int LPL = 1 << lpl_log2, LPW = 64 >> lpl_log2;
@@ -419,8 +477,8 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
     const long base = lv ? line * nx : 0;
     const int iy = lv ? (int)(line % ny) : 0, iz = lv ? (int)(line / ny) : 0;
     double xm[NB + 1][NCH][K], yo[NB + 1][NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], xL[NCH][K], xR[NCH][K], ic[NCH][K];
-    const bool fuse = fz.p != nullptr && cg->its > 0;
-    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
+    const bool fuse = fz.p != nullptr && (lean.st ? lean_fuse : cg->its > 0);
+    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? (lean.st ? lean_beta : cg->beta) : 0.0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
@@ -831,11 +889,18 @@ __global__ __launch_bounds__(256) void k_cg_update(double *__restrict__ x, doubl
 }
 // fused CG: r -= alpha q and |r|^2 only (x_sol and p are updated by the next x pass)
 __global__ __launch_bounds__(256) void k_cg_rupdate(double *__restrict__ r, const double *__restrict__ q, long n,
-                                                    const CgScalars *__restrict__ cg, double *__restrict__ partials)
+                                                    const CgScalars *__restrict__ cg, double *__restrict__ partials, CgLean lean)
 {
     __shared__ double sred[4];
     if (cg->done) return;
-    const double alpha = cg->alpha;
+    double alpha;
+    if (lean.st) {                                              // lean CG: this kernel consumes the p.q partials (FIN_PAP)
+        const double pq = strided_total(lean.partials, lean.count, sred);
+        const bool brk = fabs(pq) < 1e-30;
+        alpha = brk ? 0.0 : lean.st->rr2[lean.par] / pq;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { lean.st->pAp = pq; lean.st->pend = 0; if (brk) lean.st->done = 1; else lean.st->alpha = alpha; }
+        if (brk) return;
+    } else alpha = cg->alpha;
     double s = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
         const double rn = r[i] - alpha * q[i];
