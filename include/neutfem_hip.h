@@ -167,7 +167,7 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  * "xcd" (default 0) gives each XCD one contiguous range of y/z tiles (measured: no gain at 256^3);
  * "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
  * "cg_lean" (default 1) drops the two finalize launches of a CG iteration on undivided meshes (consumer-side reduction,
- * bit-identical), "cg_lean_grid" = blocks of its residual update. */
+ * bit-identical; meshes of at most "cg_lean_max_cells" cells, default 4 Mi), "cg_lean_grid" = blocks of its residual update. */
 int nf_set_option(nf_handle h, const char *key, long value);
 
 /* raw device-memory helpers so callers without torch can drive the *_dev entry points */

@@ -118,6 +118,7 @@ struct nf_team {
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
     int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID;
+    long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
 };
@@ -965,7 +966,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
     // lean variant on top of the fused one (undivided mesh, no RCCL): no k_finalize launches, see CgLean.  Row 0 of the partial
     // buffer holds the p.q partials of the last direction pass, row 1 the |r|^2 partials of k_cg_rupdate.
-    const bool lean = fused && T->opt_lean && team_is_single(T) && !T->rccl_reduce;
+    const bool lean = fused && T->opt_lean && team_is_single(T) && !T->rccl_reduce && T->slabs[0]->N <= T->lean_max_cells;
     // every block of the next x pass sums the |r|^2 partials; fewer partials (cg_lean_grid) cost k_cg_rupdate more than they save (measured)
     const int gru = lean ? grid_for(T->slabs[0]->nphi, 256, T->opt_lean_grid) : 0;
     double *row1 = T->d_partials + T->partial_stride;
@@ -1867,6 +1868,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
     else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
     else if (!strcmp(key, "cg_lean")) T->opt_lean = value != 0;
+    else if (!strcmp(key, "cg_lean_max_cells")) T->lean_max_cells = value;
     else if (!strcmp(key, "cg_lean_grid")) T->opt_lean_grid = (int)std::max(1L, std::min(1024L, value));
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;
