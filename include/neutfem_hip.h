@@ -171,6 +171,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
 int nf_set_option(nf_handle h, const char *key, long value);
 
 /* raw device-memory helpers so callers without torch can drive the *_dev entry points */
+/* free / total HBM of a device (hipMemGetInfo): sizing of decompositions, leak checks */
+int nf_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
 int nf_dev_alloc(nf_handle h, size_t bytes, void **ptr_dev);
 int nf_dev_free(nf_handle h, void *ptr_dev);
 int nf_memcpy_h2d(nf_handle h, void *dst_dev, const void *src_host, size_t bytes);

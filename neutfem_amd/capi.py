@@ -16,7 +16,7 @@ SYMBOLS = [
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_coarsen", "nf_prolong", "nf_timers", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy",
-    "nf_set_option", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
+    "nf_set_option", "nf_mem_info", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
 
 
@@ -80,6 +80,7 @@ def load():
     L.nf_time_schur_apply.argtypes = [vp, C.c_int, C.c_int, dp]
     L.nf_time_device_copy.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.nf_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.nf_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.nf_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.nf_dev_free.argtypes = [vp, vp]
     L.nf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -288,6 +289,14 @@ class HipSolver:
 
     def time_device_copy(self, nbytes, reps=20):
         v = C.c_double(); self._chk(self.L.nf_time_device_copy(self.h, int(nbytes), reps, C.byref(v))); return v.value
+
+
+def mem_info(device=0):
+    """(free, total) bytes of HBM on `device`"""
+    L = load(); f, t = C.c_size_t(), C.c_size_t()
+    if L.nf_mem_info(device, C.byref(f), C.byref(t)) != 0:
+        raise RuntimeError(L.nf_last_error().decode())
+    return f.value, t.value
 
 
 def device_count():

@@ -1875,6 +1875,15 @@ int nf_set_option(nf_handle S, const char *key, long value)
 }
 
 // ---- raw memory helpers ------------------------------------------------------------------------
+int nf_mem_info(int device, size_t *free_bytes, size_t *total_bytes)
+{
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(NF_ERR_ARG, "nf_mem_info: device %d out of range", device); }
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return NF_OK;
+}
 int nf_dev_alloc(nf_handle S, size_t bytes, void **p)
 {
     if (!S || !p) return fail(NF_ERR_ARG, "nf_dev_alloc: bad arguments");

@@ -144,3 +144,29 @@ def test_coarsen_and_prolong_entry_points():
     with pytest.raises(RuntimeError, match="do not divide"):
         b.coarsen(5, 2, 2)
     c.close(); a.close(); b.close()
+
+
+def test_no_device_memory_leak():
+    """create / build / solve (every path that allocates lazily: coarse team, diagonal cache + device outer loop, CMFD, adjoint,
+    currents, slab team with comm stream) / destroy, 12 times: free HBM must come back"""
+    from neutfem_amd import capi
+    from neutfem_amd.capi import HipTeam
+    inp = synthetic_inputs(24, 20, 64, 2, seed=4)
+
+    def cycle():
+        s = make_hip(inp); s.set_tol(1e-6, 1e-6, 1e-6, 12, 500)
+        s.solve_keff(True, [2, 2, 2]); s.solve_keff(use_diag=True); s.solve_keff(use_diag=True, use_cmfd=True)
+        s.solve_adjoint(True, True); s.get_J(); s.coarsen(2, 2, 2).close(); s.close()
+        t = HipTeam(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], [(0, 32), (32, 64)])
+        t.set_linear_solver(6)
+        for a, ty in zip(inp["bc_attr"], inp["bc_type"]):
+            t.set_bc(int(a), int(ty))
+        t.upload_xs_global(inp["D"], inp["SigR"], inp["NSF"], inp["Chi"], inp["SigS"]); t.build()
+        t.set_tol(1e-6, 1e-6, 1e-6, 6, 500); t.solve_keff(True, [2, 2, 2]); t.get_J_local(); t.close()
+
+    cycle()                                                       # first cycle: runtime pools, code objects
+    free0, total = capi.mem_info(0)
+    for _ in range(12):
+        cycle()
+    free1, _ = capi.mem_info(0)
+    assert free0 - free1 < 32 << 20, f"leaked {(free0 - free1) / 2**20:.1f} MiB over 12 cycles"
