@@ -1189,6 +1189,16 @@ int nf_get_J(nf_handle S, double *J_host)
     return NF_OK;
 }
 
+// ChebyshevAccel(15, 0.98) coefficient tables a_n, b_n (src/solvers.cpp:664-700), shared by the direct and adjoint iterations
+static const int CHEB_NMAX = 15;
+static const double CHEB_SIGMA = 0.98;
+static void cheb_tables(double *ca, double *cbv)
+{
+    const double sigma = CHEB_SIGMA, Gm = std::acosh(2. / sigma - 1.);
+    ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
+    for (int i = 2; i < CHEB_NMAX; ++i) { ca[i] = std::cosh((i - 1) * Gm) / std::cosh(i * Gm); cbv[i] = std::cosh((i - 2) * Gm) / std::cosh(i * Gm); }
+}
+
 // ---- SolveCoarse (src/NeutFEM.cpp:2380-2611) ---------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff, int *n_outer);
 
@@ -1522,10 +1532,9 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     const double cg_tol = direct ? 1e-14 : o->tol_flux;           // SetTolerance forwards tol_flux (:334)
     const int cg_max = direct ? (int)std::min<long>(20 * Ntot + 50, 2000000000L) : o->max_inner;   // CG ends in <= n steps in exact arithmetic
     // ChebyshevAccel(15, 0.98), src/solvers.cpp:664-700
-    const int nmax = 15; const double sigma = 0.98;
+    const int nmax = CHEB_NMAX; const double sigma = CHEB_SIGMA;
     double ca[16], cbv[16];
-    { const double Gm = std::acosh(2. / sigma - 1.); ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
-      for (int i = 2; i < nmax; ++i) { ca[i] = std::cosh((i - 1) * Gm) / std::cosh(i * Gm); cbv[i] = std::cosh((i - 2) * Gm) / std::cosh(i * Gm); } }
+    cheb_tables(ca, cbv);
     int cheb_it = 0;
     T->hist_k.clear(); T->hist_dk.clear(); T->hist_dphi.clear(); T->hist_cg.clear();
     T->last_outer = 0; T->last_cg_total = 0;
@@ -1660,10 +1669,9 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
     const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (team_is_single(T) && NPtot < 200);
     const double cg_tol = direct ? 1e-14 : o->tol_flux;
     const int cg_max = direct ? (int)std::min<long>(20 * NPtot + 50, 2000000000L) : o->max_inner;
-    const int nmax = 15; const double sigma = 0.98;
+    const int nmax = CHEB_NMAX; const double sigma = CHEB_SIGMA;
     double ca[16], cbv[16];
-    { const double Gm = std::acosh(2. / sigma - 1.); ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
-      for (int i = 2; i < nmax; ++i) { ca[i] = std::cosh((i - 1) * Gm) / std::cosh(i * Gm); cbv[i] = std::cosh((i - 2) * Gm) / std::cosh(i * Gm); } }
+    cheb_tables(ca, cbv);
     int cheb_it = 0;
     T->hist_k.clear(); T->hist_dk.clear(); T->hist_dphi.clear(); T->hist_cg.clear();
     T->last_outer = 0; T->last_cg_total = 0;
