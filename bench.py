@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed converged solve (k-eff, pcm)")
     ap.add_argument("--no-parity", action="store_true", help="skip the small-mesh GPU-vs-oracle parity probe")
     ap.add_argument("--no-small", action="store_true", help="skip the small BASELINE configs (0-2)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the extra line for BASELINE config 4 (synthetic 512^3 x 8 groups on this one GPU)")
     ap.add_argument("--loopback-slabs", type=int, default=1, help="z-slabs per process (>1: exercise the slab path on one GPU)")
     return ap.parse_args()
 
@@ -107,7 +108,11 @@ def small_configs(device):
         o.get_D()[...] = z["D"]; o.get_SigR()[...] = z["SigR"]; o.get_NSF()[...] = z["NSF"]; o.get_Chi()[...] = z["Chi"]; o.get_SigS()[...] = z["SigS"]
         o.BuildMatrices(); o.set_tol(1e-5, 1e-4, 1e-4, 200, 1000)
         t0 = time.perf_counter(); ko = o.SolveKeff(coarse, f if coarse else [], diag); tcpu = time.perf_counter() - t0
+        pg, po = s.get_phi().ravel(), o.phi_dofs().ravel()
+        ho = o.history()
         res.append(dict(config=label, cells=int(s.ne), outers=int(n), coarse_outers=int(h["coarse_outer"]), cg_iterations=int(h["cg"].sum()),
+                        outers_oracle=int(ho["n_outer"]), cg_iterations_oracle=int(ho["cg"].sum()),
+                        flux_rel_l2_vs_oracle=float(_np.linalg.norm(pg - po) / _np.linalg.norm(po)),
                         solve_ms=round(best * 1e3, 2), outer_iters_per_s=round(n / best, 1), keff=k, keff_oracle=ko,
                         pcm_vs_oracle=round(1e5 * abs(k - ko) / ko, 4), pcm_vs_literature=round(1e5 * (1 / float(z["kref"]) - 1 / k), 1),
                         cpu_oracle_ms=round(tcpu * 1e3, 1)))
@@ -227,22 +232,31 @@ def main():
             passes.append(dict(name=nm, kernel=kern[d], launches=c * per, avg_ms=ms / c / per,
                                alg_bytes=algorithmic_bytes(dim, Nl, nJd[d]) + (fused_bytes if d == 0 else 0.0)))
     dom = max(passes, key=lambda p: p["avg_ms"])
-    # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    # command, gfx950 x2 read correction; profiles/r01_d_pmc_traffic_256cube.json, made by profiles/collect.sh).  Per-cell figure x cells of this run.
-    traffic = None
+    # HBM traffic of that kernel from the PMC counters.  Counters cannot be read inside this process: the figure comes from separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/collect.sh; gfx950 x2 read correction), stored per
+    # cell in a committed profile; `traffic_source` says which one, so a stale profile is visible.  null when no profile matches the run.
+    traffic, traffic_source = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_256cube.json")) as f:
-            pmc = json.load(f)["kernels"]
-        key = {"schur_x": "k_schur_x<2, 2, true, 0>", "schur_y": "k_schur_s<8, 1, false, 0>", "schur_z": "k_schur_s<8, 2, false, 0>"}[dom["name"]]
-        if a.n == 256 and a.case == "iaea3d" and slabs_total == 1:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_256cube.json"))[-1]
+        with open(os.path.join(ROOT, "profiles", prof)) as f:
+            pj = json.load(f)
+        pmc = pj["kernels"]
+        import re
+        pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_s<\d+, 1,", "schur_z": r"k_schur_s<\d+, 2,"}[dom["name"]]
+        hits = [k for k in pmc if re.match(pat, k)]
+        key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None
+        if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:
             traffic = round(pmc[key]["hbm_bytes_per_cell"] * N)
+            traffic_source = dict(file="profiles/" + prof, kernel=key, measured_in_this_run=False,
+                                  how="separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE) of `python bench.py`; bytes per cell x cells of this run",
+                                  tag=pj.get("tag"), commit=pj.get("commit"))
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
     ca, cms = s.profile("schur_apply")
     apply_bytes = (24.0 * Nl + 40.0 * sum(nJd[d] for d in range(dim))) * a.loopback_slabs + fused_bytes
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
                     alg_bytes_per_launch=dom["alg_bytes"], fused_cg_vector_bytes_in_x_pass=fused_bytes,
                     schur_apply=dict(avg_ms=round(cms / max(ca, 1), 4), alg_bytes=apply_bytes,
                                      achieved=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9, 1),
@@ -278,23 +292,77 @@ def main():
         t1 = time.perf_counter(); kc, nc = s.solve_keff(True, case["coarse_factors"]); tcv = time.perf_counter() - t1
         out["converged"] = dict(keff=kc, outers=nc, seconds=round(tcv, 2), kref_literature=1.029096,
                                 pcm_vs_kref=round(1e5 * (1 / 1.029096 - 1 / kc), 2),
-                                keff_one_gpu_256cube=1.0284219916, pcm_vs_one_gpu=round(1e5 * abs(kc - 1.0284219916) / 1.0284219916, 3) if a.n == 256 else None,
                                 note="reference driver settings: set_tol(1e-5,1e-4,1e-4,200,1000), coarse init; the resampled 1.48 cm mesh does not "
                                      "align with the 20 cm assemblies, hence the offset from the literature value (physics sanity only)")
+        # k of the undivided (one-GPU) solve of the same workload, for the decomposed runs to be compared with: taken from a
+        # previous N = 1 line of this script -- the one this box wrote (gpurun_out/bench_keff_n1.json) or, failing that, the newest
+        # committed profiles/r*_bench_256cube.json.  Never a literal in the source; at N = 1 nothing is compared (it would be a self-comparison).
+        wl = out["config"]["workload"]
+        n1_file = os.path.join(ROOT, "gpurun_out", "bench_keff_n1.json")
+        if rank == 0 and slabs_total == 1:
+            try:
+                os.makedirs(os.path.dirname(n1_file), exist_ok=True)
+                with open(n1_file, "w") as f:
+                    json.dump(dict(workload=wl, keff=kc, outers=nc), f)
+            except OSError:
+                pass
+        elif rank == 0:
+            ref = None
+            try:
+                with open(n1_file) as f:
+                    j = json.load(f)
+                if j["workload"] == wl:
+                    ref = (j["keff"], "gpurun_out/bench_keff_n1.json (N=1 run on this box)")
+            except (OSError, ValueError, KeyError):
+                pass
+            if ref is None:
+                for fn in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_256cube.json")), reverse=True):
+                    try:
+                        with open(os.path.join(ROOT, "profiles", fn)) as f:
+                            j = json.loads(f.read().strip().splitlines()[-1])
+                        if j["n_gpus"] == 1 and j["config"]["workload"] == wl and "converged" in j:
+                            ref = (j["converged"]["keff"], "profiles/" + fn); break
+                    except (OSError, ValueError, KeyError):
+                        continue
+            if ref is not None:
+                out["converged"].update(keff_one_gpu=ref[0], keff_one_gpu_source=ref[1], pcm_vs_one_gpu=round(1e5 * abs(kc - ref[0]) / ref[0], 4))
     if rank == 0 and slabs_total == 1:
         # ---- CPU baseline: bounded sample of the same workload on the host (1 core) -------------------------------
         if a.cpu_sample_iters > 0:
+            note("CPU baseline (oracle, 1 core)")
             o = make_oracle(case)
             rhs = np.abs(np.random.default_rng(0).standard_normal(o.n_phi))
             o.set_tol(0.0, 0.0, 1e-4, 1, a.cpu_sample_iters)    # CG tol 0 -> exactly cpu_sample_iters iterations
-            t1 = time.perf_counter(); _, _, its = o.solve_group(0, rhs); tc = time.perf_counter() - t1
+            # (i) CG iterations alone: Schur apply + the vector updates of src/solvers.cpp:577-636, no J back-solve
+            t1 = time.perf_counter(); phi_c, _, its = o.solve_group(0, rhs, with_J=False); tc = time.perf_counter() - t1
             per_it = tc / max(its, 1)
-            cpu_outer_s = per_it * cg_per_outer                  # the CG iterations are >99 % of an outer iteration
-            out["cpu_baseline"] = dict(value=round(1.0 / cpu_outer_s, 6), unit="outer-iters/s", cores=1, kind="port",
-                                       sample=f"{its} CG iterations (Schur apply + vector updates + J back-solve) of group 0 on the same "
-                                              f"{case['name']} operator = {tc:.1f} s on one host core; extrapolated with the "
-                                              f"{cg_per_outer:.0f} CG iterations per outer measured in the timed GPU steps",
-                                       sec_per_cg_iteration=round(per_it, 4))
+            # (ii) what SchurSolver::Solve adds once per group solve: J = -A^-1 B^T phi (:227-228), and, in the reference as it is
+            # written, SetMatrices -> SparseLU(A_g) again for every group of every outer (:163; here a banded LDL^T, cheaper)
+            o.set_tol(0.0, 0.0, 1e-4, 1, 1)
+            t1 = time.perf_counter(); o.solve_group(0, rhs, with_J=False); t_one = time.perf_counter() - t1
+            t1 = time.perf_counter(); o.solve_group(0, rhs, with_J=True); t_J = max(time.perf_counter() - t1 - t_one, 0.0)
+            o.set_refactor_each_solve(1)
+            t1 = time.perf_counter(); o.solve_group(0, rhs, with_J=False); t_fac = max(time.perf_counter() - t1 - t_one, 0.0)
+            o.set_refactor_each_solve(0)
+            sane = per_it * cg_per_outer + ng * t_J              # factor once per BuildMatrices
+            faithful = sane + ng * t_fac                         # re-factor A for every group and outer
+            out["cpu_baseline"] = dict(value=round(1.0 / sane, 6), unit="outer-iters/s", cores=1, kind="port", mode="ref-sane",
+                                       sample=f"{its} CG iterations (Schur apply + vector updates, no J back-solve) of group 0 on the same "
+                                              f"{case['name']} operator = {tc:.1f} s on one host core; one J back-solve = {t_J:.2f} s and one "
+                                              f"re-factorisation of A_g = {t_fac:.2f} s timed separately; an outer iteration = "
+                                              f"{cg_per_outer:.0f} CG iterations (measured in the timed GPU steps) + {ng} J back-solves"
+                                              f" (+ {ng} factorisations in ref-faithful mode)",
+                                       sec_per_cg_iteration=round(per_it, 4), sec_per_J_backsolve=round(t_J, 3), sec_per_factorisation=round(t_fac, 3),
+                                       ref_sane=dict(value=round(1.0 / sane, 6), sec_per_outer=round(sane, 1), what="A factored once per BuildMatrices"),
+                                       ref_faithful=dict(value=round(1.0 / faithful, 6), sec_per_outer=round(faithful, 1),
+                                                         what="A re-factored for every group of every outer as src/solvers.cpp:163 does "
+                                                              "(banded LDL^T instead of Eigen's general SparseLU: favourable to the reference)"))
+            # operator parity at the BENCHMARK size: one Schur apply of the GPU against the oracle on the same vector
+            if a.case == "iaea3d" and not a.no_parity:
+                xr = np.random.default_rng(1).standard_normal(o.n_phi)
+                yo_, yg_ = o.schur_apply(0, xr), s.schur_apply(0, xr)
+                out["parity_at_bench_size"] = dict(what="S_0 x on one random vector, GPU vs CPU oracle, full benchmark mesh", cells=int(N),
+                                                   max_rel_err=float(np.abs(yg_ - yo_).max() / np.abs(yo_).max()))
             del o
         # ---- small-mesh parity probe against the oracle (same code path, tight tolerances) ---------------------
         if not a.no_parity and a.case == "iaea3d":
@@ -310,9 +378,42 @@ def main():
     # ---- the other BASELINE configs (small, launch-latency bound): timed with the reference drivers' own settings ----
     if rank == 0 and slabs_total == 1 and not a.no_small:
         out["other_configs"] = small_configs(local)
+    s.close()
+    # ---- BASELINE configs[4] (synthetic 512^3, 8 groups, fixed work of 50 CG iterations per group solve) on this ONE GPU,
+    # so that the driver's run times it too.  Needs ~165 GB of HBM and ~75 GB of host memory for the case arrays: skipped when the
+    # box has less.  The headline (`value`, `config.workload`) stays the IAEA-3D 256^3 case above.
+    if rank == 0 and world == 1 and slabs_total == 1 and a.case == "iaea3d" and a.n == 256 and not a.no_c5:
+        try:
+            free_b, _tot = capi.mem_info(local)
+            with open("/proc/meminfo") as f:
+                avail_kb = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable"))
+            if free_b >= 180e9 and avail_kb * 1024 >= 110e9:
+                note("C5: synthetic 512^3 x 8 groups (generation + upload + BuildMatrices take ~20 s)")
+                c5 = cases.synthetic_checkerboard(512, 8)
+                s5 = make_solver(c5, local)
+                del c5["SigS"]
+                s5.set_tol(0.0, 0.0, 1e-4, 1, 50); s5.solve_keff()                      # warm-up outer
+                s5.set_tol(0.0, 0.0, 1e-4, 2, 50); s5.profile_reset()
+                s5._chk(s5.L.nf_synchronize(s5.h)); t1 = time.perf_counter()
+                k5, n5 = s5.solve_keff(profile=True)
+                s5._chk(s5.L.nf_synchronize(s5.h)); t5 = time.perf_counter() - t1
+                N5 = s5.ne; nJ5 = {0: 513 * 512 * 512, 1: 512 * 513 * 512, 2: 512 * 512 * 513}
+                ps = []
+                for d, nm in enumerate(["schur_x", "schur_y", "schur_z"]):
+                    c, ms = s5.profile(nm)
+                    if c:
+                        fb = 32.0 * N5 * (1.0 - 1.0 / 50.0) if d == 0 else 0.0
+                        ps.append(dict(name=nm, avg_ms=round(ms / c, 4), achieved=round((algorithmic_bytes(3, N5, nJ5[d]) + fb) / (ms / c * 1e-3) / 1e9, 1)))
+                out["c5_single_gpu"] = dict(workload=c5["name"] + ", full Schur path, exactly 50 CG iterations per group solve", cells=int(N5), groups=8,
+                                            steps=int(n5), value=round(n5 / t5, 4), unit="outer-iters/s", ms_per_step=round(t5 / n5 * 1e3, 1),
+                                            keff_after_steps=k5, passes=ps, peak_GBps=HBM_PEAK_GBS)
+                s5.close()
+            else:
+                out["c5_single_gpu"] = dict(skipped=f"needs >= 180 GB free HBM and >= 110 GB free host memory (have {free_b / 1e9:.0f} / {avail_kb * 1024 / 1e9:.0f})")
+        except Exception as e:                                                          # never lose the headline line to the extra one
+            out["c5_single_gpu"] = dict(error=str(e)[:300])
     if rank == 0:
         print(json.dumps(out))
-    s.close()
     if dist is not None:
         dist.destroy_process_group()
 

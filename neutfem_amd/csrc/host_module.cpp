@@ -100,7 +100,7 @@ public:
     void ResetFlux()
     {
         std::fill(Phi_.begin(), Phi_.end(), 1.0); std::fill(PhiAdj_.begin(), PhiAdj_.end(), 1.0);
-        has_valid_keff_ = false;
+        has_valid_keff_ = false; has_valid_adjoint_ = false;     // src/NeutFEM.cpp:347-354
         if (h_) nf_reset_flux(h_);
     }
     std::string GetSolverName() const
@@ -176,7 +176,7 @@ public:
         chk(nf_solve_adjoint(h_, &o, normalize_to_direct ? 1 : 0, use_direct_keff ? 1 : 0, &k, &nout));
         chk(nf_get_phi_adj(h_, PhiAdj_.data()));
         if (verb_ >= VerbosityLevel::NORMAL) std::cout << "  k-eff adjoint = " << std::fixed << std::setprecision(8) << k << std::defaultfloat << std::endl;
-        last_keff_adj_ = k;
+        last_keff_adj_ = k; has_valid_adjoint_ = true;            // src/NeutFEM.cpp:2075
         return k;
     }
     void BuildDiagonalCache() { need_built("build_diagonal_cache"); chk(nf_build_diagonal_cache(h_)); }
@@ -213,7 +213,8 @@ public:
             for (int g = 0; g < ng_; ++g) scalars("Flux_g" + std::to_string(g), [&](long e) { return Phi_[g * nphi_ + e * nloc_]; });
             scalars("Flux_total", [&](long e) { double t = 0; for (int g = 0; g < ng_; ++g) t += Phi_[g * nphi_ + e * nloc_]; return t; });
         }
-        (void)export_adjoint;                                     // has_valid_adjoint_ is never true here (adjoint off-path)
+        if (export_adjoint && has_valid_adjoint_)                 // src/NeutFEM.cpp:2206-2214: only after a SolveAdjoint
+            for (int g = 0; g < ng_; ++g) scalars("Flux_adj_g" + std::to_string(g), [&](long e) { return PhiAdj_[g * nphi_ + e * nloc_]; });
         if (export_current) {
             need_built("ExportVTK(export_current=True)");
             std::vector<double> J((size_t)ng_ * nJ_);
@@ -289,7 +290,7 @@ private:
     LinearSolverType solver_ = LinearSolverType::BICGSTAB; bool solver_pushed_ = false;   // src/NeutFEM.cpp:126 vs solvers.cpp:68
     double tol_keff_ = 1e-5, tol_flux_ = 1e-5, tol_L2_ = 1e-5; int max_outer_ = 200, max_inner_ = 1000;
     VerbosityLevel verb_ = VerbosityLevel::NORMAL; double cmfd_omega_ = 1.0;
-    bool has_valid_keff_ = false;
+    bool has_valid_keff_ = false, has_valid_adjoint_ = false;
 };
 
 PYBIND11_MODULE(_neutfem_eigen, m)

@@ -121,6 +121,13 @@ struct nf_team {
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
+    int opt_fuse3 = 1; long fuse3_max_cells = 4L << 20;   // fused-direction CG (two launches per iteration) up to this many cells
+    int opt_resident = 1; long resident_max_dofs = 5000;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
+    int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
+    int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
+    // coarse twin of the team (SolveCoarse): built on the first coarse-mesh start and kept until the cross sections, the boundary
+    // conditions or the team change -- creating and factoring it costs more than solving it on the benchmark meshes
+    std::vector<nf_solver *> cc; int cc_f[3] = {0, 0, 0};
 };
 
 struct nf_solver {
@@ -144,6 +151,7 @@ struct nf_solver {
     double *d_phi_adj = nullptr;                        // adjoint flux, ng*nphi (allocated by the first adjoint solve)
     int has_valid_adjoint = 0; double last_keff_adj = 1.0;
     std::vector<double *> d_Ms;                          // ng*ng
+    const double **d_Ms_tab = nullptr;                   // the same ng*ng pointers on the device (resident kernel)
     double *d_L[3] = {nullptr, nullptr, nullptr}, *d_DR[3] = {nullptr, nullptr, nullptr}, *d_D0[3] = {nullptr, nullptr, nullptr};
     long nlines[3] = {0, 0, 0};
     double *d_Sinv = nullptr;
@@ -156,6 +164,7 @@ struct nf_solver {
     double *d_phi = nullptr, *d_raw = nullptr;          // current iterate / raw group solutions, ng*N
     double *d_p0 = nullptr, *d_p1 = nullptr;            // Chebyshev history
     double *d_tf = nullptr, *d_rhs = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
+    double *d_p2 = nullptr, *d_qy = nullptr, *d_qz = nullptr;   // fused-direction CG (k_apply3): second buffer of the p pair, y / z outputs
     bool raw_valid = false, raw_is_diag = false;
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
     CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
@@ -168,6 +177,15 @@ struct nf_solver {
 };
 
 const char *nf_last_error(void) { return g_err.c_str(); }
+
+static void coarse_cache_drop(nf_team *T)
+{
+    if (!T || T->cc.empty()) return;
+    std::string keep = g_err;
+    std::vector<nf_solver *> cc; cc.swap(T->cc);
+    for (int i = (int)cc.size() - 1; i >= 0; --i) if (cc[i]) nf_destroy(cc[i]);
+    g_err = keep;
+}
 
 int nf_device_count(void)
 {
@@ -263,7 +281,8 @@ static ModeTab mode_tab(const nf_solver *S, int d)
 // ---- team management ---------------------------------------------------------------------------
 static long slab_partial_need(const nf_solver *S)
 {
-    return (std::max<long>(RED_GRID, std::max(S->nlines[0], (long)((S->nx + 7) / 8) * std::max(S->ny, S->nz))) + 16) * n_modes(S);
+    // the fused-direction launch (k_apply3) writes one partial per x, y and z block of the same launch
+    return (std::max<long>(RED_GRID, S->nlines[0] + (long)((S->nx + 7) / 8) * ((long)S->ny + S->nz)) + 16) * n_modes(S);
 }
 static int team_alloc(nf_team *T)
 {
@@ -285,7 +304,7 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
-    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_ost); dfree(T->d_hist);
+    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
     if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
     if (T->ev_xchg) (void)hipEventDestroy(T->ev_xchg);
@@ -317,6 +336,8 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     S->nx = nxb - 1; S->ny = nyb > 1 ? nyb - 1 : 1; S->nz = nzb > 1 ? nzb - 1 : 1;
     S->dim = S->nz > 1 ? 3 : (S->ny > 1 ? 2 : 1);               // src/FEM.cpp:33-35
     if ((if_lo || if_hi) && (S->dim != 3 || S->nz < 3)) { delete S; return fail(NF_ERR_ARG, "a slab needs a 3D mesh with at least 3 z-planes"); }
+    // a 3D mesh reads y_breaks(i+1) - y_breaks(i) (src/FEM.cpp:43-47): one y cell still needs its two breaks (Eigen asserts there)
+    if (S->dim == 3 && (nyb < 2 || !yb)) { delete S; return fail(NF_ERR_ARG, "nf_create: a 3D mesh needs at least 2 y breaks (got %d)", nyb); }
     S->N = (long)S->nx * S->ny * S->nz;
     S->n1 = m + 1; S->nloc = 1; for (int t = 0; t < S->dim; ++t) S->nloc *= S->n1;
     S->nphi = S->N * S->nloc; S->nb = std::min(k, m);
@@ -387,6 +408,7 @@ int nf_destroy(nf_handle S)
     if (!S) return NF_OK;
     (void)hipSetDevice(S->device);
     nf_team *T = S->team;
+    coarse_cache_drop(T);
     if (T && T->stream) (void)hipStreamSynchronize(T->stream);
     for (int d = 0; d < 3; ++d) { dfree(S->d_Dt[d]); dfree(S->d_Dh[d]); }
     dfree(S->d_cm); dfree(S->d_cmJ); dfree(S->d_cmsc);
@@ -394,13 +416,14 @@ int nf_destroy(nf_handle S)
     dfree(S->d_D); dfree(S->d_SigR); dfree(S->d_NSF); dfree(S->d_Chi);
     for (auto &p : S->d_SigS) dfree(p);
     for (auto &p : S->d_Ms) dfree(p);
+    dfree(S->d_Ms_tab);
     dfree(S->d_Cd); dfree(S->d_Mf); dfree(S->d_Mchi); dfree(S->d_phi_adj); dfree(S->d_Sinv);
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
     dfree(S->d_Jz); dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
     dfree(S->d_phi); dfree(S->d_raw); dfree(S->d_p0); dfree(S->d_p1);
-    dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q);
+    dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q); dfree(S->d_p2); dfree(S->d_qy); dfree(S->d_qz);
     if (T) {
         T->slabs.erase(std::remove(T->slabs.begin(), T->slabs.end(), S), T->slabs.end());
         for (size_t i = 0; i < T->slabs.size(); ++i) T->slabs[i]->slab_index = (int)i;
@@ -425,6 +448,7 @@ int nf_link_slabs(nf_handle *handles, int n)
         if (i > 0 && (!S->if_lo || !handles[i - 1]->if_hi)) return fail(NF_ERR_ARG, "nf_link_slabs: slabs %d/%d lack the shared interface flag", i - 1, i);
     }
     nf_team *T = S0->team;
+    for (int i = 0; i < n; ++i) coarse_cache_drop(handles[i]->team);
     for (int i = 1; i < n; ++i) {
         nf_solver *S = handles[i];
         team_free(S->team);
@@ -505,7 +529,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
+    K("last_path", T->last_path); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
 #undef K
     return -1;
 }
@@ -514,6 +538,7 @@ int nf_set_bc(nf_handle S, int attr, int bc_type)
 {
     if (!S || attr < 0 || attr >= 8) return fail(NF_ERR_ARG, "nf_set_bc: bad attribute %d", attr);
     S->bc_set[attr] = 1; S->bc_type[attr] = bc_type;
+    coarse_cache_drop(S->team);
     return NF_OK;
 }
 
@@ -523,6 +548,10 @@ int nf_upload_xs(nf_handle S, const double *D, const double *SigR, const double 
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const size_t NN = (size_t)S->N * S->ng, B = NN * sizeof(double);
+    // the device copies are overwritten from here on: whatever was built from the old ones is stale until the next nf_build,
+    // also when this upload is refused below (a refused upload leaves the handle un-built, never half-valid)
+    S->xs_uploaded = false; S->built = false; S->diag_valid = false; S->cmfd_init = false;
+    coarse_cache_drop(S->team);
     NFCHK(dalloc(&S->d_D, NN)); NFCHK(dalloc(&S->d_SigR, NN)); NFCHK(dalloc(&S->d_NSF, NN)); NFCHK(dalloc(&S->d_Chi, NN));
     HIPCHK(hipMemcpyAsync(S->d_D, D, B, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(S->d_SigR, SigR, B, hipMemcpyHostToDevice, st));
@@ -567,6 +596,7 @@ int nf_build(nf_handle S)
     if (!S) return fail(NF_ERR_ARG, "nf_build: null handle");
     if (!S->xs_uploaded) return fail(NF_ERR_STATE, "nf_build: call nf_upload_xs first");
     HIPCHK(hipSetDevice(S->device));
+    coarse_cache_drop(S->team);
     hipStream_t st = S->team->stream;
     const int ng = S->ng; const long N = S->N, NP = S->nphi; const size_t NN = (size_t)N * ng;
     NFCHK(dalloc(&S->d_Cd, (size_t)NP * ng)); NFCHK(dalloc(&S->d_Mf, (size_t)NP * ng)); NFCHK(dalloc(&S->d_Mchi, (size_t)NP * ng));
@@ -609,6 +639,14 @@ int nf_build(nf_handle S)
                                S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * nl, nl, lo, hi, so);
         }
     }
+    {
+        std::vector<const double *> tab(S->d_Ms.begin(), S->d_Ms.end());
+        NFCHK(dalloc(&S->d_Ms_tab, tab.size()));
+        HIPCHK(hipMemcpyAsync(S->d_Ms_tab, tab.data(), tab.size() * sizeof(double *), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                         // `tab` is host stack memory
+    }
+    // Chebyshev history of the power iteration (two multigroup vectors): allocated here, not inside the outer loop
+    if (!S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NP * ng)); NFCHK(dalloc(&S->d_p1, (size_t)NP * ng)); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     S->built = true; S->diag_valid = false; S->cmfd_init = false;   // src/NeutFEM.cpp:454-456
@@ -941,6 +979,83 @@ int nf_team_schur_apply(nf_handle S, int g, const double *const *x_dev, double *
     return NF_OK;
 }
 
+#ifdef NF_STAMPS
+static long long *g_stamps = nullptr;
+extern "C" int nf_debug_stamps(long long *out48) { if (!g_stamps) return -1; return hipMemcpy(out48, g_stamps, 48 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2; }
+#endif
+// ---- fused-direction apply (k_apply3): geometry of the launch ------------------------------------
+struct Fuse3Plan { bool ok = false; int nch = 1, vec = 1, seg = 8, B = 256, nblocks = 0; size_t lds = 0; Apply3 A; };
+static Fuse3Plan fuse3_plan(const nf_solver *S)
+{
+    Fuse3Plan P; memset(&P.A, 0, sizeof P.A);
+    const int K = 2, modes = n_modes(S);
+    int lanes = (S->nx + K - 1) / K, lpl_log2 = 0;
+    while ((1 << lpl_log2) < lanes && lpl_log2 < 6) ++lpl_log2;
+    const int LPL = 1 << lpl_log2, LPW = 64 / LPL;
+    const int nch = (S->nx + LPL * K - 1) / (LPL * K);
+    if (nch > 4) return P;                                       // x lines beyond 512 cells: registers of a 512-thread block
+    P.nch = nch <= 1 ? 1 : nch <= 2 ? 2 : 4; P.vec = S->nx % 2 == 0;
+    const int nmax = std::max(S->dim >= 2 ? S->ny : 1, S->dim == 3 ? S->nz : 1);
+    P.seg = S->nb > 0 ? (nmax <= 256 ? 4 : 8) : 8;
+    int B = 256;
+    for (int r = 0; r < 2; ++r) {
+        if (S->dim < r + 2) continue;
+        const int n = r == 0 ? S->ny : S->nz;
+        const int NSEG = (n + P.seg - 1) / P.seg;
+        if (NSEG > 64) return P;
+        // small meshes: narrow tiles, so that the launch spreads over many CUs (one CU pulls ~10 B/cycle; measured with in-kernel
+        // stamps at 38x38x19: 64-column tiles spent 4 us of a 6 us block in their load phase); big ones: wide rows for HBM
+        int TX = S->N <= (1L << 16) ? 8 : S->N <= (1L << 18) ? 16 : S->N <= (1L << 20) ? 32 : 64;
+        while (TX > 8 && TX * NSEG > 512) TX >>= 1;
+        while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;
+        const long nxy = (long)S->nx * S->ny;
+        P.A.n[r] = n; P.A.TX[r] = TX; P.A.NSEG[r] = NSEG; P.A.gx[r] = (S->nx + TX - 1) / TX; P.A.gy[r] = r == 0 ? S->nz : S->ny;
+        P.A.sl[r] = r == 0 ? S->nx : nxy; P.A.ostride[r] = r == 0 ? nxy : S->nx;
+        B = std::max(B, (TX * NSEG + 63) / 64 * 64);
+    }
+    P.B = B;
+    const int nw = B / 64;
+    P.A.ntask_x = (int)((S->nlines[0] + LPW - 1) / LPW); P.A.lpl_log2 = lpl_log2;
+    P.A.nbx = (int)(((long)P.A.ntask_x * modes + nw - 1) / nw);
+    P.A.nby = S->dim >= 2 ? P.A.gx[0] * P.A.gy[0] * modes : 0;
+    P.A.nbz = S->dim == 3 ? P.A.gx[1] * P.A.gy[1] * modes : 0;
+    P.nblocks = P.A.nbx + P.A.nby + P.A.nbz;
+    P.lds = (size_t)(4 * B + 64 + 16) * sizeof(double);
+    P.A.stamps = nullptr;
+#ifdef NF_STAMPS
+    { static long long *d_st = nullptr; if (!d_st) (void)hipMalloc((void **)&d_st, 48 * sizeof(long long)); P.A.stamps = d_st; g_stamps = d_st; }
+#endif
+    P.ok = true;
+    return P;
+}
+// one k_apply3 launch: q_d = S_d p for every direction; pin = the vector the iteration reads, pout = where the new p goes
+static int launch_apply3(nf_solver *S, int g, const Fuse3Plan &P, const double *pin, double *pout, double *xsol, const CgLean &lean)
+{
+    nf_team *T = S->team; hipStream_t st = T->stream;
+    const long N = S->N;
+    const Geom G = make_geom(S);
+    ModeArgs ma[3]; ModeTab mt[3];
+    double *qd[3] = { S->d_q, S->d_qy, S->d_qz };
+    for (int d = 0; d < 3; ++d) {
+        const int dd = d < S->dim ? d : 0;
+        ma[d] = mode_args(S, g, dd, 0, pin, qd[d < S->dim ? d : 0]); mt[d] = mode_tab(S, dd);
+    }
+    const double *L[3], *DR[3], *D0[3];
+    for (int d = 0; d < 3; ++d) { const int dd = d < S->dim ? d : 0; L[d] = S->d_L[dd] + g * N; DR[d] = S->d_DR[dd] + g * N; D0[d] = S->d_D0[dd] + g * S->nlines[dd]; }
+    const CgFuse fz = { const_cast<double *>(pin), S->d_r, xsol, pout };
+#define NF_A3(NCHV, VECV, NBV, SEGV) hipLaunchKernelGGL((k_apply3<NCHV, VECV, NBV, SEGV>), dim3((unsigned)P.nblocks), dim3((unsigned)P.B), P.lds, st, ma[0], ma[1], ma[2], mt[0], mt[1], mt[2], G, \
+        L[0], DR[0], D0[0], L[1], DR[1], D0[1], L[2], DR[2], D0[2], S->nx, S->ny, S->nlines[0], P.A, T->d_partials, T->d_cg, fz, lean)
+#define NF_A3_SEG(NCHV, VECV, NBV) do { if (NBV == 0 || P.seg == 8) NF_A3(NCHV, VECV, NBV, 8); else NF_A3(NCHV, VECV, NBV, (NBV == 0 ? 8 : 4)); } while (0)
+#define NF_A3_NB(NCHV, VECV) do { if (S->nb == 0) NF_A3_SEG(NCHV, VECV, 0); else if (S->nb == 1) NF_A3_SEG(NCHV, VECV, 1); else NF_A3_SEG(NCHV, VECV, 2); } while (0)
+#define NF_A3_VEC(NCHV) do { if (P.vec) NF_A3_NB(NCHV, true); else NF_A3_NB(NCHV, false); } while (0)
+    if (P.nch == 1) NF_A3_VEC(1); else if (P.nch == 2) NF_A3_VEC(2); else NF_A3_VEC(4);
+#undef NF_A3_VEC
+#undef NF_A3_NB
+#undef NF_A3_SEG
+#undef NF_A3
+    return NF_OK;
+}
+
 // ---- CG (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636) -----------------------------
 // rhs / x: per-slab pointers
 static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, const std::vector<double *> &x, double tol, int maxit,
@@ -972,10 +1087,33 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     double *row1 = T->d_partials + T->partial_stride;
     const CgLean no_lean = { nullptr, nullptr, 0, 0, 0 };
     int rc = NF_OK;
+    // fused-direction variant on top of the lean one (small / medium meshes): two launches per iteration, see k_apply3
+    Fuse3Plan f3;
+    nf_solver *S0 = T->slabs[0];
+    if (lean && T->opt_fuse3 && S0->N <= T->fuse3_max_cells) f3 = fuse3_plan(S0);
+    if (f3.ok && f3.nblocks > T->slab_cap) f3.ok = false;
+    if (f3.ok) {
+        if (!S0->d_p2) NFCHK(dalloc(&S0->d_p2, S0->nphi));
+        if (S0->dim >= 2 && !S0->d_qy) NFCHK(dalloc(&S0->d_qy, S0->nphi));
+        if (S0->dim == 3 && !S0->d_qz) NFCHK(dalloc(&S0->d_qz, S0->nphi));
+    }
     while (launched < maxit && rc == NF_OK) {
         int nb = std::min(batch, maxit - launched);
         for (int it = 0; it < nb && rc == NF_OK; ++it) {
             const int index = launched + it;                      // iteration number within this solve
+            if (f3.ok) {
+                // p lives in a pair of buffers: iteration 0 reads A = d_p as k_cg_init left it; iteration i >= 1 reads the p of
+                // iteration i-1 (A for odd i, B for even i) and writes r + beta p into the other one
+                double *A = S0->d_p, *B = S0->d_p2;
+                double *pin = (index == 0 || (index & 1)) ? A : B, *pout = pin == A ? B : A;
+                hipEvent_t ta = nullptr, tb = nullptr;
+                if (T->profile) prof_begin(T, 3, &ta, &tb);
+                rc = launch_apply3(S0, g, f3, pin, pout, x[0], CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 });
+                if (T->profile) (void)hipEventRecord(tb, T->stream);
+                hipLaunchKernelGGL(k_cg_rupdate3, dim3(gru), dim3(256), 0, T->stream, S0->d_r, (const double *)S0->d_q, (const double *)(S0->dim >= 2 ? S0->d_qy : nullptr),
+                                   (const double *)(S0->dim == 3 ? S0->d_qz : nullptr), S0->nphi, T->d_cg, row1, CgLean{ T->d_cg, T->d_partials, f3.nblocks, index & 1, 0 });
+                continue;
+            }
             if (lean) T->slabs[0]->lean = CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 };
             rc = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
             if (lean) T->slabs[0]->lean = no_lean;
@@ -1011,13 +1149,16 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     }
     for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = CgFuse{ nullptr, nullptr, nullptr };
     NFCHK(rc);
-    if (fused)
-        for (int i = 0; i < ns; ++i)
-            hipLaunchKernelGGL(k_cg_flush, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], (const double *)T->slabs[i]->d_p, T->slabs[i]->nphi, T->d_cg);
     if (launched == 0) {
         HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
         HIPCHK(hipStreamSynchronize(T->stream));
     }
+    if (fused)
+        for (int i = 0; i < ns; ++i) {
+            const double *plast = T->slabs[i]->d_p;
+            if (f3.ok && sc.its >= 2 && ((sc.its - 1) & 1)) plast = T->slabs[i]->d_p2;   // the direction of the last iteration (see the buffer pair above)
+            hipLaunchKernelGGL(k_cg_flush, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], plast, T->slabs[i]->nphi, T->d_cg);
+        }
     HIPCHK(hipGetLastError());
     if (T->profile) prof_collect(T);
     if (!std::isfinite(sc.rr)) return fail(NF_ERR_NUMERIC, "CG produced a non-finite residual (group %d)", g);
@@ -1263,10 +1404,24 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     }
     std::vector<nf_handle> C(ns, nullptr);
     int rc = NF_OK;
-    for (int i = 0; i < ns && rc == NF_OK; ++i) rc = coarsen_slab(T->slabs[i], rx, ry, rz, &C[i]);
-    if (rc == NF_OK && ns > 1) rc = nf_link_slabs(C.data(), ns);
+    const bool reuse = (int)T->cc.size() == ns && T->cc_f[0] == rx && T->cc_f[1] == ry && T->cc_f[2] == rz;
+    if (reuse) {
+        for (int i = 0; i < ns && rc == NF_OK; ++i) { C[i] = T->cc[i]; rc = nf_reset_flux(C[i]); }   // a fresh coarse solver starts from phi = 1, k = 1 (:2458)
+    } else {
+        coarse_cache_drop(T);
+        for (int i = 0; i < ns && rc == NF_OK; ++i) rc = coarsen_slab(T->slabs[i], rx, ry, rz, &C[i]);
+        if (rc == NF_OK && ns > 1) rc = nf_link_slabs(C.data(), ns);
+        if (rc == NF_OK) { T->cc = C; T->cc_f[0] = rx; T->cc_f[1] = ry; T->cc_f[2] = rz; }
+        else { std::string keep = g_err; for (int i = ns - 1; i >= 0; --i) if (C[i]) nf_destroy(C[i]); g_err = keep; return rc; }
+    }
     nf_team *CT = rc == NF_OK ? C[0]->team : nullptr;
-    if (CT) { CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false; }
+    if (CT) {
+        CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
+        // tuning options (nf_set_option) apply to the coarse solve as well
+        CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->resident_max_dofs = T->resident_max_dofs;
+        CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev;
+    }
     double kc = 1.0; int nout = 0;
     if (rc == NF_OK) {
         nf_keff_opts co = *o;                                    // :2460-2467
@@ -1283,10 +1438,8 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         }
         if (hipStreamSynchronize(CT->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
     }
-    std::string keep = g_err;
-    if (CT) CT->comm = nullptr;                                  // borrowed: must not be destroyed with the coarse team
-    for (int i = ns - 1; i >= 0; --i) if (C[i]) nf_destroy(C[i]);
-    if (rc != NF_OK) { g_err = keep; return rc; }
+    if (CT) { CT->comm = nullptr; CT->nproc = 1; CT->rccl_reduce = false; }   // borrowed for the solve only: never destroyed with the coarse team
+    if (rc != NF_OK) { coarse_cache_drop(T); return rc; }
     *k_coarse = kc; *done = true;
     return NF_OK;
 }
@@ -1503,6 +1656,79 @@ static int solve_keff_diag_device(nf_team *T, const nf_keff_opts *o, double keff
     return NF_OK;
 }
 
+// ---- resident solve (k_resident_keff): whole power iteration of a small undivided mesh in one launch ------------------
+static bool resident_plan(const nf_solver *S, ResidentArgs *A)
+{
+    const int K = 2;
+    int lanes = (S->nx + K - 1) / K, lpl_log2 = 0;
+    while ((1 << lpl_log2) < lanes && lpl_log2 < 6) ++lpl_log2;
+    const int LPL = 1 << lpl_log2, LPW = 64 / LPL;
+    if (S->nx > LPL * K) return false;                           // one chunk per x line (nx <= 128)
+    const int seg = S->nb > 0 ? 4 : 8;
+    for (int r = 0; r < 2; ++r) {
+        if (S->dim < r + 2) { A->n[r] = 1; A->TX[r] = 8; A->NSEG[r] = 1; A->gx[r] = A->gy[r] = 0; A->sl[r] = A->ostride[r] = 0; continue; }
+        const int n = r == 0 ? S->ny : S->nz;
+        const int NSEG = (n + seg - 1) / seg;
+        if (NSEG > 64) return false;
+        int TX = 64;
+        while (TX > 8 && TX * NSEG > 512) TX >>= 1;
+        while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;
+        const long nxy = (long)S->nx * S->ny;
+        A->n[r] = n; A->TX[r] = TX; A->NSEG[r] = NSEG; A->gx[r] = (S->nx + TX - 1) / TX; A->gy[r] = r == 0 ? S->nz : S->ny;
+        A->sl[r] = r == 0 ? S->nx : nxy; A->ostride[r] = r == 0 ? nxy : S->nx;
+    }
+    A->lpl_log2 = lpl_log2; A->ntask_x = (int)((S->nlines[0] + LPW - 1) / LPW);
+    return true;
+}
+static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, const double *ca, const double *cbv, double sigma,
+                               double cg_tol, int cg_max, double *keff_out)
+{
+    nf_solver *S = T->slabs[0];
+    const int ng = S->ng; hipStream_t st = T->stream;
+    ResidentArgs A; memset(&A, 0, sizeof A);
+    if (!resident_plan(S, &A)) return fail(NF_ERR_STATE, "resident solve: mesh not eligible");
+    A.G = make_geom(S); A.ng = ng; A.dim = S->dim; A.nmodes = n_modes(S); A.N = S->N; A.nphi = S->nphi;
+    for (int d = 0; d < 3; ++d) {
+        const int dd = d < S->dim ? d : 0;
+        A.ma[d] = mode_args(S, 0, dd, 0, S->d_p, S->d_q); A.mt[d] = mode_tab(S, dd);
+        A.L[d] = S->d_L[dd]; A.DR[d] = S->d_DR[dd]; A.D0[d] = S->d_D0[dd]; A.nlines[d] = S->nlines[dd];
+    }
+    A.Mf = S->d_Mf; A.Chi = S->d_Chi; A.Ms = S->d_Ms_tab;
+    A.phi = S->d_phi; A.raw = S->d_raw; A.p0 = S->d_p0; A.p1 = S->d_p1; A.tf = S->d_tf; A.r = S->d_r; A.p = S->d_p; A.q = S->d_q;
+    A.keff0 = keff0; A.tol_keff = o->tol_keff; A.tol_flux = o->tol_flux; A.cg_tol = cg_tol; A.cg_max = cg_max; A.max_outer = o->max_outer;
+    A.ca1 = ca[1];
+    for (int i = 2; i < 15; ++i) { A.a3[i] = (4. / sigma) * ca[i]; A.cb[i] = cbv[i]; }
+    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer)); T->hist_cap = o->max_outer; }
+    if (T->hist_cg_cap < o->max_outer * ng) { NFCHK(dalloc(&T->d_hist_cg, (size_t)o->max_outer * ng)); T->hist_cg_cap = o->max_outer * ng; }
+    if (!T->d_rout) NFCHK(dalloc(&T->d_rout, 1));
+    A.hist = T->d_hist; A.hist_cg = T->d_hist_cg; A.out = T->d_rout;
+    // the kernel indexes its history with max_outer as the row length
+    const int B = 512; const size_t lds = (size_t)(5 * B + 64 + 16) * sizeof(double);
+#define NF_RES(VECV, NBV) hipLaunchKernelGGL((k_resident_keff<VECV, NBV>), dim3(1), dim3(B), lds, st, A)
+    const bool vec = S->nx % 2 == 0;
+    if (S->nb == 0) { if (vec) NF_RES(true, 0); else NF_RES(false, 0); }
+    else if (S->nb == 1) { if (vec) NF_RES(true, 1); else NF_RES(false, 1); }
+    else { if (vec) NF_RES(true, 2); else NF_RES(false, 2); }
+#undef NF_RES
+    HIPCHK(hipGetLastError());
+    ResidentOut ro;
+    HIPCHK(hipMemcpyAsync(&ro, T->d_rout, sizeof ro, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int n = ro.n_outer;
+    T->hist_k.resize(n); T->hist_dk.resize(n); T->hist_dphi.resize(n); T->hist_cg.resize((size_t)n * ng);
+    if (n > 0) {
+        HIPCHK(hipMemcpy(T->hist_k.data(), T->d_hist, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_dk.data(), T->d_hist + o->max_outer, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_dphi.data(), T->d_hist + 2 * (size_t)o->max_outer, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_cg.data(), T->d_hist_cg, (size_t)n * ng * sizeof(int), hipMemcpyDeviceToHost));
+        for (int g = 0; g < ng; ++g) T->last_its[g] = T->hist_cg[(size_t)(n - 1) * ng + g];
+    }
+    T->last_outer = n; T->last_cg_total = ro.cg_total;
+    if (ro.status == 2) return fail(NF_ERR_NUMERIC, "power iteration diverged (outer %d: k=%g dphi=%g)", n - 1, T->hist_k[n - 1], T->hist_dphi[n - 1]);
+    *keff_out = ro.keff;
+    return NF_OK;
+}
+
 // ---- SolveKeff (src/NeutFEM.cpp:1627-1815) -----------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, int *n_outer)
 {
@@ -1542,12 +1768,26 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     if (use_diag && single && !use_cmfd && !T->rccl_reduce && T->opt_outer_dev && o->max_outer > 0) {
         NFCHK(solve_keff_diag_device(T, o, keff, ca, cbv, sigma, &keff));
         HIPCHK(hipStreamSynchronize(T->stream));
-        T->profile = false;
+        T->profile = false; T->last_path = 1;
         S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = true;
         T->has_valid_keff = 1; T->last_keff = keff;
         if (keff_out) *keff_out = keff;
         if (n_outer) *n_outer = T->last_outer;
         return NF_OK;
+    }
+    T->last_path = 0;
+    {
+        ResidentArgs probe;
+        if (single && !use_diag && !use_cmfd && !direct && !T->rccl_reduce && T->opt_resident && o->max_outer > 0 && S0->nphi <= T->resident_max_dofs &&
+            resident_plan(S0, &probe)) {
+            T->last_path = 2; T->profile = false;
+            NFCHK(solve_keff_resident(T, o, keff, ca, cbv, sigma, cg_tol, cg_max, &keff));
+            S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = false; S0->jz_valid = false;
+            T->has_valid_keff = 1; T->last_keff = keff;
+            if (keff_out) *keff_out = keff;
+            if (n_outer) *n_outer = T->last_outer;
+            return NF_OK;
+        }
     }
     ScatterArgs sa; sa.ng = ng;
     double hout[4];
@@ -1868,8 +2108,15 @@ int nf_set_option(nf_handle S, const char *key, long value)
 {
     if (!S || !key) return fail(NF_ERR_ARG, "nf_set_option: bad arguments");
     nf_team *T = S->team;
-    if (!strcmp(key, "s_tx")) T->opt_s_tx = (int)value;
-    else if (!strcmp(key, "s_seg")) T->opt_s_seg = (int)value;
+    // tuning overrides of the y/z line kernel: 0 = automatic; the partial-sum buffer is sized for >= 8 columns per block
+    // (slab_partial_need) and the kernel is instantiated for these segment lengths only
+    if (!strcmp(key, "s_tx")) {
+        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(NF_ERR_ARG, "nf_set_option: s_tx must be 0 (auto), 8, 16, 32 or 64");
+        T->opt_s_tx = (int)value;
+    } else if (!strcmp(key, "s_seg")) {
+        if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32) return fail(NF_ERR_ARG, "nf_set_option: s_seg must be 0 (auto), 4, 8, 16 or 32");
+        T->opt_s_seg = (int)value;
+    }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
@@ -1877,6 +2124,10 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
     else if (!strcmp(key, "cg_lean")) T->opt_lean = value != 0;
     else if (!strcmp(key, "cg_lean_max_cells")) T->lean_max_cells = value;
+    else if (!strcmp(key, "resident")) T->opt_resident = value != 0;
+    else if (!strcmp(key, "resident_max_dofs")) T->resident_max_dofs = value;
+    else if (!strcmp(key, "cg_fuse3")) T->opt_fuse3 = value != 0;
+    else if (!strcmp(key, "cg_fuse3_max_cells")) T->fuse3_max_cells = value;
     else if (!strcmp(key, "cg_lean_grid")) T->opt_lean_grid = (int)std::max(1L, std::min(1024L, value));
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
     return NF_OK;

@@ -14,6 +14,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// in-kernel cycle stamps: diagnostic builds only (-DNF_STAMPS, scratch library; never in the shipped one)
+#ifdef NF_STAMPS
+#define NF_STAMP(buf, i) do { if (buf) (buf)[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define NF_STAMP(buf, i) do { } while (0)
+#endif
+
 namespace nf {
 
 // device-resident state of one CG solve (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636)
@@ -124,10 +131,12 @@ __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgSca
 // k_cg_lean_rr applies the FIN_RR step alone (idempotent: same inputs, same parity slot) so that the host, which reads the
 // scalars at the end of a batch, sees the outcome of the batch's last iteration.
 struct CgLean { CgScalars *st; const double *partials; int count; int par; int first; };
-__device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred)   // 256-thread blocks; result in every thread
+__device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred)   // blocks of >= 256 threads; result in every thread
 {
+    // summed by the first 256 threads only, so that blocks of any size (and k_finalize) produce the same bits: the other
+    // threads add exact zeros
     double s = 0.0;
-    for (int i = threadIdx.x; i < cnt; i += 256) s += p[i];
+    if (threadIdx.x < 256) for (int i = threadIdx.x; i < cnt; i += 256) s += p[i];
     s = block_sum(s, sred);
     if (threadIdx.x == 0) sred[0] = s;
     __syncthreads();
@@ -453,32 +462,27 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
 // (src/solvers.cpp:609,630) -- are deferred to the next iteration's x pass, which reads p anyway: p is read once instead
 // of three times per iteration and one launch disappears.  Same operands, same expressions: bit-identical iterates.
 // The last iteration's x_sol update is applied by k_cg_flush (CgScalars::pend).
-struct CgFuse { double *p; const double *r; double *xsol; };
+// pout: where the new direction p = r + beta p goes (nullptr: in place).  The fused-direction launch (k_apply3) runs the x, y
+// and z passes of one apply side by side, so the y / z blocks must still find the old p while the x blocks write the new
+// one: they read p and r and form r + beta p themselves (mode "read-only fuse"), and the x blocks write into the other
+// buffer of a pair.  Every site evaluates fma(beta, p, r) / fma(alpha, p, x_sol): same bits everywhere.
+struct CgFuse { double *p; const double *r; double *xsol; double *pout; };
+
+// One wave-task of the x pass: 64/LPL lines, lane = (line of the task, position in the line).  Returns the lane's share of x.y.
 template <int K, int NCH, bool VEC, int NB>
-__global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
-                                                 const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
-                                                 int first, int last, double *__restrict__ partials,
-                                                 const CgScalars *__restrict__ cg, CgFuse fz, CgLean lean)
+__device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
+                                               const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2, int first,
+                                               long task, int lane, bool active, bool fuse, double f_alpha, double f_beta, const CgFuse &fz)
 {
     static_assert(K == 2, "two cells per lane and chunk");
-    __shared__ double sred[4];
-    if (cg && cg->done) return;
-    bool lean_fuse = false; double lean_beta = 0.0;
-    if (lean.st && !lean.first) {                               // lean CG: this pass consumes the |r|^2 partials (FIN_RR)
-        if (lean_rr_step(lean, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &lean_beta)) return;
-        lean_fuse = true;
-    }
-    const ModeArgs ma = select_mode(ma0, mt, blockIdx.y, NB + 1);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int LPL = 1 << lpl_log2, LPW = 64 >> lpl_log2;
     const int li = lane & (LPL - 1), sub = lane >> lpl_log2;
-    const long line = ((long)blockIdx.x * 4 + wave) * LPW + sub;
-    const bool lv = line < nlines;
+    const long line = task * LPW + sub;
+    const bool lv = active && line < nlines;
     const long base = lv ? line * nx : 0;
     const int iy = lv ? (int)(line % ny) : 0, iz = lv ? (int)(line / ny) : 0;
     double xm[NB + 1][NCH][K], yo[NB + 1][NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], xL[NCH][K], xR[NCH][K], ic[NCH][K];
-    const bool fuse = fz.p != nullptr && (lean.st ? lean_fuse : cg->its > 0);
-    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? (lean.st ? lean_beta : cg->beta) : 0.0;
+    double *pw = fz.pout ? fz.pout : fz.p;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
@@ -497,14 +501,14 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
                 double r0, r1, s0, s1;
                 ld2(fz.r, mo, ok, VEC, r0, r1, ok2);
                 ld2(fz.xsol, mo, ok, VEC, s0, s1, ok2);
-                s0 += f_alpha * xm[q][ch][0]; s1 += f_alpha * xm[q][ch][1];
-                xm[q][ch][0] = r0 + f_beta * xm[q][ch][0]; xm[q][ch][1] = r1 + f_beta * xm[q][ch][1];
+                s0 = fma(f_alpha, xm[q][ch][0], s0); s1 = fma(f_alpha, xm[q][ch][1], s1);
+                xm[q][ch][0] = fma(f_beta, xm[q][ch][0], r0); xm[q][ch][1] = fma(f_beta, xm[q][ch][1], r1);
                 if (VEC) {
                     if (ok) { *reinterpret_cast<double2 *>(fz.xsol + mo) = make_double2(s0, s1);
-                              *reinterpret_cast<double2 *>(fz.p + mo) = make_double2(xm[q][ch][0], xm[q][ch][1]); }
+                              *reinterpret_cast<double2 *>(pw + mo) = make_double2(xm[q][ch][0], xm[q][ch][1]); }
                 } else {
-                    if (ok) { fz.xsol[mo] = s0; fz.p[mo] = xm[q][ch][0]; }
-                    if (ok2) { fz.xsol[mo + 1] = s1; fz.p[mo + 1] = xm[q][ch][1]; }
+                    if (ok) { fz.xsol[mo] = s0; pw[mo] = xm[q][ch][0]; }
+                    if (ok2) { fz.xsol[mo + 1] = s1; pw[mo + 1] = xm[q][ch][1]; }
                 }
             }
         }
@@ -600,6 +604,27 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
             }
         }
     }
+    return dot;
+}
+
+template <int K, int NCH, bool VEC, int NB>
+__global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+                                                 const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
+                                                 int first, int last, double *__restrict__ partials,
+                                                 const CgScalars *__restrict__ cg, CgFuse fz, CgLean lean)
+{
+    __shared__ double sred[4];
+    if (cg && cg->done) return;
+    bool lean_fuse = false; double lean_beta = 0.0;
+    if (lean.st && !lean.first) {                               // lean CG: this pass consumes the |r|^2 partials (FIN_RR)
+        if (lean_rr_step(lean, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &lean_beta)) return;
+        lean_fuse = true;
+    }
+    const ModeArgs ma = select_mode(ma0, mt, blockIdx.y, NB + 1);
+    const bool fuse = fz.p != nullptr && (lean.st ? lean_fuse : cg->its > 0);
+    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? (lean.st ? lean_beta : cg->beta) : 0.0;
+    const double dot = schur_x_task<K, NCH, VEC, NB>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first, (long)blockIdx.x * 4 + (threadIdx.x >> 6),
+                                                     threadIdx.x & 63, true, fuse, f_alpha, f_beta, fz);
     if (last && partials) {
         const double s = block_sum(dot, sred);
         if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
@@ -623,35 +648,29 @@ struct SlabArgs {
     double *clo, *chi;                        // per line (mode 1 outputs)
     double *jz;                               // mode 3: J = -u on the slab's own z faces [(face) * nx * ny + line] (Sol_J_, src/solvers.cpp:228)
 };
+// One tile (TX columns x one line each, NSEG segments) of a y / z pass.  tid = thread index within the tile; threads with
+// act == false only keep the barriers company.  acc: accumulate into y (the x pass ran before) or store the increment alone
+// (fused-direction launch: every direction has an output vector of its own).  fro ("read-only fuse"): the input vector is
+// r + beta x, formed on the fly (see CgFuse).  Returns the thread's share of x.y.
 template <int SEG, int DIR, bool SLAB, int NB>
-__global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
-                          const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
-                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz)
+__device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
+                                               const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
+                                               unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
+                                               const SlabArgs &sa, const CgFuse &fz, bool fuse, bool fro, double f_alpha, double f_beta, bool acc,
+                                               long long *stamp = nullptr)
 {
-    extern __shared__ double sm[];
-    if (cg && cg->done) return;
-    const ModeArgs ma = select_mode(ma0, mt, blockIdx.z, NB + 1);
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
-    // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
-    // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread
-    const bool fuse = SLAB && NB == 0 && sa.mode == 1 && fz.p != nullptr && cg->its > 0;
-    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
     double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
-    double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T, *sred = sm + 4 * T + TX;
-    const int tid = threadIdx.x, ixl = tid % TX, seg = tid / TX;
-    // XCD-aware tile order (experiment, sa.xcd): hardware deals consecutive workgroups round-robin to the 8 XCDs; remap so that
-    // each XCD works on one contiguous range of tiles
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (sa.xcd) {
-        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
-    }
+    double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T;
+    act = act && tid < T;
+    const int ixl = act ? tid % TX : 0, seg = act ? tid / TX : 0;
     const int ix = bx * TX + ixl;
-    const bool valid = ix < nx;
+    const bool valid = act && ix < nx;
     long base = (long)by * outer_stride + ix;
     const long lineid = (long)by * nx + ix;
-    const long lm = SLAB ? (long)blockIdx.z * ((long)nx * gridDim.y) + lineid : 0;   // slab exchange planes: [mode][line]
+    const long lm = SLAB ? (long)bz * ((long)nx * gy) + lineid : 0;   // slab exchange planes: [mode][line]
+    const long roff = fro ? (long)(fz.r - fz.p) : 0;                 // r relative to the input vector (same offset for every moment)
     // slab chain: cells [fs, fs+n) of the local line; x just outside the chain is real data (edge cells)
     double x_before = 0.0, x_after = 0.0, a_lo = 0.0, a_hi = 0.0, u_lo = 0.0, u_hi = 0.0, xe_lo = 0.0, xe_hi = 0.0;
     long edge_lo = 0, edge_hi = 0;
@@ -666,7 +685,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
             // edge), towards the separator xL / xR -- for RT0 all four are the cell value itself
             if (sa.if_lo) {
                 a_lo = sa.alo[lineid]; x_before = x[edge_lo];
-                if (fuse) { if (seg == 0) fz.xsol[edge_lo] += f_alpha * x_before; x_before = fz.r[edge_lo] + f_beta * x_before; }
+                if (fuse) { if (seg == 0) fz.xsol[edge_lo] = fma(f_alpha, x_before, fz.xsol[edge_lo]); x_before = fma(f_beta, x_before, fz.r[edge_lo]); }
                 xe_lo = x_before;
                 if (NB > 0) {
                     const double g1 = ma.Gc[0] * ma.x[1][edge_lo], g2 = NB > 1 ? ma.Gc[1] * ma.x[2][edge_lo] : 0.0;
@@ -677,7 +696,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
             }
             if (sa.if_hi) {
                 a_hi = sa.ahi[lineid]; x_after = x[edge_hi];
-                if (fuse) { if (seg == 0) fz.xsol[edge_hi] += f_alpha * x_after; x_after = fz.r[edge_hi] + f_beta * x_after; }
+                if (fuse) { if (seg == 0) fz.xsol[edge_hi] = fma(f_alpha, x_after, fz.xsol[edge_hi]); x_after = fma(f_beta, x_after, fz.r[edge_hi]); }
                 xe_hi = x_after;
                 if (NB > 0) {
                     const double g1 = ma.Gc[0] * ma.x[1][edge_hi], g2 = NB > 1 ? ma.Gc[1] * ma.x[2][edge_hi] : 0.0;
@@ -699,15 +718,17 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
         const long a = base + (long)c * sl;
         xv[i] = ok ? x[a] : 0.0;
         if (SLAB && fuse && ok) {
-            if (i < SEG) fz.xsol[a] += f_alpha * xv[i];             // owned cell; the overlap cell (i == SEG) belongs to the next segment
-            xv[i] = fz.r[a] + f_beta * xv[i];
+            if (i < SEG) fz.xsol[a] = fma(f_alpha, xv[i], fz.xsol[a]);   // owned cell; the overlap cell (i == SEG) belongs to the next segment
+            xv[i] = fma(f_beta, xv[i], fz.r[a]);
         }
+        if (!SLAB && fro && ok) xv[i] = fma(f_beta, xv[i], x[a + roff]);
         if (SLAB && valid && c == n) xv[i] = x_after;
         Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) Rv[i] = ok ? DR[a] : 0.0;
         if (NB > 0) {
-            const double v1 = ok ? ma.x[1][a] : 0.0;
-            const double v2 = (NB > 1 && ok) ? ma.x[2][a] : 0.0;
+            double v1 = ok ? ma.x[1][a] : 0.0;
+            double v2 = (NB > 1 && ok) ? ma.x[2][a] : 0.0;
+            if (!SLAB && fro && ok) { v1 = fma(f_beta, v1, ma.x[1][a + roff]); if (NB > 1) v2 = fma(f_beta, v2, ma.x[2][a + roff]); }
             if (i < SEG) {
                 x1[i] = v1; if (NB > 1) x2[i] = v2;
                 // cell coordinates for 1/c_e = D / factor_dir
@@ -741,9 +762,11 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     }
 #pragma unroll
     for (int i = 0; i < SEG; ++i) { const double ti = NB == 0 ? xv[i] - xv[i + 1] : t[NB > 0 ? i : 0]; lz = ti - Lv[i] * lz; P = -Lv[i] * P; }
-    sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz;
-    if (seg == 0) sZ0[ixl] = x_before - xL0;
+    NF_STAMP(stamp, 4);
+    if (act) { sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz; }
+    if (act && seg == 0) sZ0[ixl] = x_before - xL0;
     __syncthreads();
+    NF_STAMP(stamp, 5);
     if (SLAB && fuse && valid) {                                 // every read of the old p in this block is behind the barrier
 #pragma unroll
         for (int i = 0; i < SEG; ++i) if (c0 + i < n) fz.p[base + (long)(c0 + i) * sl] = xv[i];
@@ -758,13 +781,15 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     double Q = 1.0, lu = 0.0;
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
-    sA2[seg * TX + ixl] = Q; sB2[seg * TX + ixl] = lu;
+    if (act) { sA2[seg * TX + ixl] = Q; sB2[seg * TX + ixl] = lu; }
     // y is only needed by the output stage: issue its loads here so they fly during the barrier + backward scan
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (valid && c < n && wr) ? y[base + (long)c * sl] : 0.0; }
+    for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (acc && valid && c < n && wr) ? y[base + (long)c * sl] : 0.0; }
+    NF_STAMP(stamp, 6);
     __syncthreads();
+    NF_STAMP(stamp, 7);
     double u = 0.0;
-    for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];
+    if (act) for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { u = w[i] - Lv[i + 1] * u; w[i] = u; }
     const double ulo = zin * dinv_s - Lv[0] * w[0];             // u at the lower face of this segment
@@ -780,12 +805,12 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                 y[a] = yv; dot += xv[i] * yv;
                 if (NB > 0) {
                     const double v = ma.Gc[0] * x1[i] * ma.iM[0] * icv[i] - (ma.eL[0] * lo + ma.eR[0] * w[i]);
-                    const double y1 = ma.y[1][a] + ma.Ta * ma.Gc[0] * v;
+                    const double y1 = (acc ? ma.y[1][a] : 0.0) + ma.Ta * ma.Gc[0] * v;
                     ma.y[1][a] = y1; dot += x1[i] * y1;
                 }
                 if (NB > 1) {
                     const double v = ma.Gc[1] * x2[i] * ma.iM[1] * icv[i] - (ma.eL[1] * lo + ma.eR[1] * w[i]);
-                    const double y2 = ma.y[2][a] + ma.Ta * ma.Gc[1] * v;
+                    const double y2 = (acc ? ma.y[2][a] : 0.0) + ma.Ta * ma.Gc[1] * v;
                     ma.y[2][a] = y2; dot += x2[i] * y2;
                 }
             }
@@ -803,7 +828,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                 if (sa.if_hi) sa.jz[(long)(fs + n + 1) * nxy + lineid] = -sa.uhi[lm];
             }
         }
-        return;
+        return 0.0;
     }
     if (SLAB) {
         // chain end values: u_first by the segment-0 thread, u_last by the thread owning chain cell n-1
@@ -850,10 +875,138 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
             }
         }
     }
-    if (last && partials) {
-        const double s = block_sum(dot, sred);
-        if (tid == 0) partials[((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx] = s;
+    return dot;
+}
+
+template <int SEG, int DIR, bool SLAB, int NB>
+__global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+                          const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
+                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz)
+{
+    extern __shared__ double sm[];
+    if (cg && cg->done) return;
+    const ModeArgs ma = select_mode(ma0, mt, blockIdx.z, NB + 1);
+    // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
+    // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread
+    const bool fuse = SLAB && NB == 0 && sa.mode == 1 && fz.p != nullptr && cg->its > 0;
+    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
+    // XCD-aware tile order (experiment, sa.xcd): hardware deals consecutive workgroups round-robin to the 8 XCDs; remap so that
+    // each XCD works on one contiguous range of tiles
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (sa.xcd) {
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
     }
+    const double dot = schur_s_tile<SEG, DIR, SLAB, NB>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
+                                                        (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
+    if (SLAB && sa.mode == 3) return;
+    if (last && partials) {
+        double *sred = sm + 4 * TX * NSEG + TX;
+        const double s = block_sum(dot, sred);
+        if (threadIdx.x == 0) partials[((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused-direction Schur apply for small and medium meshes (undivided, lean CG).  Below a few million cells a CG iteration is
+// a chain of short dependent kernels and their number, not the bytes, sets the pace.  The x, y and z passes of one apply
+// depend on each other only through the read-modify-write of y, so here they run side by side in ONE launch, each direction
+// into an output vector of its own (qx = C p + X p, qy = Y p, qz = Z p; k_cg_rupdate3 forms (qx + qy) + qz, the same bits as the
+// three accumulating passes).  The deferred x_sol += alpha p, p = r + beta p rides in the x blocks, which write the new p into
+// the other buffer of a pair; the y / z blocks form r + beta p from the old one on the fly (CgFuse).  A CG iteration is then two
+// dependent launches (k_apply3, k_cg_rupdate3) instead of four; every block of a launch first sums the partials of the
+// launch before it (lean CG), so the scalars alpha, beta and the stop test need no launch of their own.
+// Blocks [0, nbx) do the x lines (one wave-task per wave), [nbx, nbx+nby) one y tile each, the rest one z tile each.
+struct Apply3 {
+    int nbx, nby, nbz;                  // blocks per role
+    int ntask_x, lpl_log2;              // x: wave-tasks per transverse mode
+    int n[2], TX[2], NSEG[2], gx[2], gy[2]; long sl[2], ostride[2];   // y (index 0) and z (index 1) tiles
+    long long *stamps;                  // diagnostic builds (-DNF_STAMPS): in-kernel cycle stamps of three blocks, else unused
+};
+template <int NCH, bool VEC, int NB, int SEG>
+__global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, ModeArgs maz0, ModeTab mtx, ModeTab mty, ModeTab mtz, Geom G,
+                                                const double *__restrict__ Lx, const double *__restrict__ DRx, const double *__restrict__ D0x,
+                                                const double *__restrict__ Ly, const double *__restrict__ DRy, const double *__restrict__ D0y,
+                                                const double *__restrict__ Lz, const double *__restrict__ DRz, const double *__restrict__ D0z,
+                                                int nx, int ny, long nlines_x, Apply3 A, double *__restrict__ partials,
+                                                const CgScalars *__restrict__ cg, CgFuse fz, CgLean lean)
+{
+    extern __shared__ double sm[];
+    double *sred = sm + 4 * (int)blockDim.x + 64;                // behind the largest tile's scan arrays (4 T + TX doubles, T <= blockDim, TX <= 64)
+    long long *stamp = nullptr;
+#ifdef NF_STAMPS
+    if (A.stamps && threadIdx.x == 0) {
+        if (blockIdx.x == 0) stamp = A.stamps; else if (blockIdx.x == (unsigned)A.nbx) stamp = A.stamps + 16; else if (blockIdx.x == (unsigned)(A.nbx + A.nby)) stamp = A.stamps + 32;
+    }
+    long long st_r0 = 0, st_0 = 0, st_1 = 0;
+    if (stamp) { st_r0 = (long long)__builtin_amdgcn_s_memrealtime(); st_0 = (long long)__builtin_readcyclecounter(); }
+#endif
+    if (cg->done) return;
+#ifdef NF_STAMPS
+    if (stamp) st_1 = (long long)__builtin_readcyclecounter();
+#endif
+    bool fuse = false; double f_beta = 0.0;
+    if (!lean.first) {                                           // FIN_RR of the previous iteration: beta, stop tests
+        if (lean_rr_step(lean, blockIdx.x == 0 && threadIdx.x == 0, sred, &f_beta)) return;
+        fuse = true;
+    }
+    const double f_alpha = fuse ? cg->alpha : 0.0;
+    NF_STAMP(stamp, 2);
+    const unsigned b = blockIdx.x;
+    double dot = 0.0;
+    if (b < (unsigned)A.nbx) {
+        const int nw = blockDim.x >> 6;
+        const long gt = (long)b * nw + (threadIdx.x >> 6);      // global wave-task: mode-major
+        const int mode = (int)(gt / A.ntask_x);
+        const bool active = mode < mtx.n;
+        const ModeArgs ma = select_mode(max0, mtx, active ? mode : 0, NB + 1);
+        dot = schur_x_task<2, NCH, VEC, NB>(ma, G, Lx, DRx, D0x, nx, ny, nlines_x, A.lpl_log2, 1, gt % A.ntask_x, threadIdx.x & 63, active,
+                                            fuse, f_alpha, f_beta, fz);
+    } else {
+        const int r = b < (unsigned)(A.nbx + A.nby) ? 0 : 1;
+        const unsigned t = b - A.nbx - (r ? A.nby : 0);
+        const unsigned bx = t % A.gx[r], by = (t / A.gx[r]) % A.gy[r], bz = t / (A.gx[r] * A.gy[r]);
+        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = 0; sa.alo = sa.ahi = sa.ulo = sa.uhi = nullptr; sa.clo = sa.chi = sa.jz = nullptr;
+        if (r == 0) {
+            const ModeArgs ma = select_mode(may0, mty, bz, NB + 1);
+            dot = schur_s_tile<SEG, 1, false, NB>(ma, G, Ly, DRy, D0y, A.n[0], A.sl[0], A.ostride[0], nx, A.TX[0], A.NSEG[0], bx, by, bz, A.gy[0],
+                                                  (int)threadIdx.x, true, sm, sa, fz, false, fuse, f_alpha, f_beta, false, stamp);
+        } else {
+            const ModeArgs ma = select_mode(maz0, mtz, bz, NB + 1);
+            dot = schur_s_tile<SEG, 2, false, NB>(ma, G, Lz, DRz, D0z, A.n[1], A.sl[1], A.ostride[1], nx, A.TX[1], A.NSEG[1], bx, by, bz, A.gy[1],
+                                                  (int)threadIdx.x, true, sm, sa, fz, false, fuse, f_alpha, f_beta, false, stamp);
+        }
+    }
+    NF_STAMP(stamp, 8);
+    const double sdot = block_sum(dot, sred);
+    if (threadIdx.x == 0) partials[b] = sdot;
+    NF_STAMP(stamp, 9);
+#ifdef NF_STAMPS
+    if (stamp) { stamp[13] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[12] = st_r0; stamp[0] = st_0; stamp[1] = st_1; }
+#endif
+}
+// r -= alpha ((qx + qy) + qz), |r|^2 partials; consumes the x.y partials of k_apply3 (FIN_PAP).  qy / qz may be null (1D / 2D).
+__global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, const double *__restrict__ qx, const double *__restrict__ qy,
+                                                     const double *__restrict__ qz, long n, const CgScalars *__restrict__ cg,
+                                                     double *__restrict__ partials, CgLean lean)
+{
+    __shared__ double sred[4];
+    if (cg->done) return;
+    const double pq = strided_total(lean.partials, lean.count, sred);
+    const bool brk = fabs(pq) < 1e-30;
+    const double alpha = brk ? 0.0 : lean.st->rr2[lean.par] / pq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { lean.st->pAp = pq; lean.st->pend = 0; if (brk) lean.st->done = 1; else lean.st->alpha = alpha; }
+    if (brk) return;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        double q = qx[i];
+        if (qy) q += qy[i];
+        if (qz) q += qz[i];
+        const double rn = r[i] - alpha * q;
+        r[i] = rn; s += rn * rn;
+    }
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -880,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_cg_update(double *__restrict__ x, doubl
     const double alpha = cg->alpha;
     double s = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-        x[i] += alpha * p[i];
+        x[i] = fma(alpha, p[i], x[i]);
         const double rn = r[i] - alpha * q[i];
         r[i] = rn; s += rn * rn;
     }
@@ -914,14 +1067,14 @@ __global__ void k_cg_flush(double *__restrict__ x, const double *__restrict__ p,
 {
     if (!cg->pend) return;
     const double alpha = cg->alpha;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] += alpha * p[i];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] = fma(alpha, p[i], x[i]);
 }
 __global__ __launch_bounds__(256) void k_cg_pupdate(double *__restrict__ p, const double *__restrict__ r, long n,
                                                     const CgScalars *__restrict__ cg)
 {
     if (cg->done) return;
     const double beta = cg->beta;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) p[i] = r[i] + beta * p[i];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) p[i] = fma(beta, p[i], r[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1112,6 +1265,173 @@ __global__ __launch_bounds__(256) void k_normalize_fission(const double *__restr
     }
     s = block_sum(s, sred);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident solve: the whole SolveKeff (full Schur path: power iteration, Gauss-Seidel group sweep, CG, Chebyshev;
+// src/NeutFEM.cpp:1627-1815, src/solvers.cpp:577-636, 664-756) of a SMALL undivided mesh in ONE workgroup and ONE launch.
+// The reference's own benchmark meshes (IAEA-2D 38x38, KOEBERG 34x34, every coarse-mesh initialisation) are a few thousand
+// unknowns: as separate launches a CG iteration is 4 x ~5 us of launch and cross-chip latency for ~100 KB of data.  Here every
+// phase is separated by a workgroup barrier only; the direction passes are the same device functions as the big-mesh kernels
+// (schur_x_task, schur_s_tile: identical per-cell arithmetic), run over "virtual" tiles; reductions are fixed-order
+// (thread-strided, then wave, then across waves), so runs are reproducible; every thread derives the same scalars from them.
+struct ResidentOut { double keff; int n_outer, status, cg_total, pad; };   // status 0 ok, 2 diverged (non-finite k or dphi)
+struct ResidentArgs {
+    Geom G; int ng, dim, nmodes; long N, nphi;
+    ModeArgs ma[3]; ModeTab mt[3];          // per direction, mode 0, group 0, x -> p, y -> q; Cd and D advance with the group
+    const double *L[3], *DR[3], *D0[3]; long nlines[3];
+    const double *Mf, *Chi; const double *const *Ms;             // Ms: ng*ng table of scatter diagonals (null = empty block, :1722)
+    double *phi, *raw, *p0, *p1, *tf, *r, *p, *q;
+    int lpl_log2, ntask_x;
+    int n[2], TX[2], NSEG[2], gx[2], gy[2]; long sl[2], ostride[2];
+    double keff0, tol_keff, tol_flux, cg_tol; int cg_max, max_outer;
+    double ca1, a3[16], cb[16];
+    double *hist; int *hist_cg; ResidentOut *out;
+};
+__device__ __forceinline__ double block_total(double v, double *sred)     // fixed-order sum over the block, result in every thread
+{
+    v = block_sum(v, sred);
+    if (threadIdx.x == 0) sred[0] = v;
+    __syncthreads();
+    v = sred[0];
+    __syncthreads();
+    return v;
+}
+// all tiles of one y / z pass, nconc = blockDim / (TX NSEG) of them side by side; every thread runs every round (barriers inside)
+template <int SEG, int DIR, int NB>
+__device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, const ModeArgs &mad, int g, double *sm, const SlabArgs &sa0, const CgFuse &fz)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int T = A.TX[r] * A.NSEG[r];
+    const int nconc = nt / T, slot = tid / T, ltid = tid - slot * T;
+    const int ntiles = A.gx[r] * A.gy[r] * A.nmodes;
+    double *smt = sm + (slot < nconc ? slot : 0) * (4 * T + A.TX[r]);
+    const long N = A.N;
+    double dot = 0.0;
+    for (int t0 = 0; t0 < ntiles; t0 += nconc) {
+        const int t = t0 + slot;
+        const bool act = slot < nconc && t < ntiles;
+        const unsigned tt = act ? t : 0;
+        const unsigned bx = tt % A.gx[r], by = (tt / A.gx[r]) % A.gy[r], bz = tt / (A.gx[r] * A.gy[r]);
+        const ModeArgs ma = select_mode(mad, A.mt[DIR], bz, NB + 1);
+        dot += schur_s_tile<SEG, DIR, false, NB>(ma, A.G, A.L[DIR] + g * N, A.DR[DIR] + g * N, A.D0[DIR] + g * A.nlines[DIR], A.n[r], A.sl[r], A.ostride[r],
+                                                 A.G.nx, A.TX[r], A.NSEG[r], bx, by, bz, A.gy[r], ltid, act, smt, sa0, fz, false, false, 0.0, 0.0, true);
+        __syncthreads();                                         // the tile's scan arrays are reused by the next round
+    }
+    return dot;
+}
+template <bool VEC, int NB>
+__global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
+{
+    constexpr int SEG = NB > 0 ? 4 : 8;
+    extern __shared__ double sm[];
+    double *sred = sm + 5 * (int)blockDim.x + 64;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
+    const int ng = A.ng; const long N = A.N, NP = A.nphi, NT = NP * ng;
+    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = nullptr; sa0.clo = sa0.chi = sa0.jz = nullptr;
+    double keff = A.keff0;
+    int cheb_it = 0, n_outer = 0, status = 0, cg_total = 0;
+    double *pa = A.p0, *pb = A.p1;
+    for (int it = 0; it < A.max_outer; ++it) {
+        // total_fiss and prod_old (:1700-1707)
+        double s = 0.0;
+        for (long i = tid; i < NP; i += nt) {
+            double v = 0.0;
+            for (int g = 0; g < ng; ++g) v += A.Mf[g * NP + i] * A.phi[g * NP + i];
+            A.tf[i] = v; s += v;
+        }
+        const double prod_old = block_total(s, sred);
+        const double inv_k = 1.0 / keff;
+        for (int g = 0; g < ng; ++g) {
+            double *xsol = A.raw + (long)g * NP;
+            // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
+            s = 0.0;
+            for (long i = tid; i < NP; i += nt) {
+                double v;
+                if (NP == N) v = inv_k * (A.Chi[g * N + i] * A.tf[i]);
+                else { const double cv = A.Chi[g * N + i % N] * inv_k; v = fabs(cv) < 1e-14 ? 0.0 : cv * A.tf[i]; }
+                for (int gp = 0; gp < ng; ++gp) {
+                    const double *M = A.Ms[g * ng + gp];
+                    if (gp == g || !M) continue;
+                    v += M[i] * (gp < g ? A.raw : A.phi)[gp * NP + i];
+                }
+                xsol[i] = 0.0; A.r[i] = v; A.p[i] = v; s += v * v;
+            }
+            double rr = block_total(s, sred);
+            const double rhs_norm = sqrt(rr), tol_sq = A.cg_tol * A.cg_tol * rhs_norm * rhs_norm;
+            int its = 0, pend = 0; double alpha = 0.0, beta = 0.0;
+            const CgFuse fz = { A.p, A.r, xsol, nullptr };
+            ModeArgs mad[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { mad[d] = A.ma[d]; mad[d].D += g * N; for (int q = 0; q <= NB; ++q) mad[d].Cd[q] += g * NP; }
+            while (its < A.cg_max) {
+                const bool fuse = its > 0;
+                double dot = 0.0;
+                // ---- x lines: q = C p + X p, carrying the deferred x_sol += alpha p, p = r + beta p of the previous iteration
+                const int ntask = A.ntask_x * A.nmodes;
+                for (int gt0 = 0; gt0 < ntask; gt0 += nw) {
+                    const int gt = gt0 + wave;
+                    const bool active = gt < ntask;
+                    const int mode = active ? gt / A.ntask_x : 0;
+                    const ModeArgs ma = select_mode(mad[0], A.mt[0], mode, NB + 1);
+                    const double dx = schur_x_task<2, 1, VEC, NB>(ma, A.G, A.L[0] + g * N, A.DR[0] + g * N, A.D0[0] + g * A.nlines[0], A.G.nx, A.G.ny,
+                                                                  A.nlines[0], A.lpl_log2, 1, gt % A.ntask_x, tid & 63, active, fuse, alpha, beta, fz);
+                    if (A.dim == 1) dot += dx;
+                }
+                __syncthreads();
+                // ---- y, then z lines: accumulate into q; the last direction also gives p.q
+                if (A.dim >= 2) { const double ds = resident_s_pass<SEG, 1, NB>(A, 0, mad[1], g, sm, sa0, fz); if (A.dim == 2) dot += ds; }
+                if (A.dim == 3) dot += resident_s_pass<SEG, 2, NB>(A, 1, mad[2], g, sm, sa0, fz);
+                const double pq = block_total(dot, sred);       // src/solvers.cpp:602-606
+                pend = 0;
+                if (fabs(pq) < 1e-30) break;
+                alpha = rr / pq;
+                s = 0.0;
+                for (long i = tid; i < NP; i += nt) { const double rn = A.r[i] - alpha * A.q[i]; A.r[i] = rn; s += rn * rn; }
+                const double rr_new = block_total(s, sred);     // :613-631
+                ++its; pend = 1;
+                if (rr_new < tol_sq) { rr = rr_new; break; }
+                beta = rr_new / rr; rr = rr_new;
+            }
+            if (pend) for (long i = tid; i < NP; i += nt) xsol[i] = fma(alpha, A.p[i], xsol[i]);     // the last iteration's x_sol update
+            if (tid == 0) A.hist_cg[it * ng + g] = its;
+            cg_total += its;
+            __syncthreads();
+        }
+        // prod_new, norms (:1766-1779)
+        double sp = 0.0, sn = 0.0, sd = 0.0;
+        for (long i = tid; i < NT; i += nt) { const double v = A.raw[i], d = v - A.phi[i]; sp += A.Mf[i] * v; sn += v * v; sd += d * d; }
+        const double prod_new = block_total(sp, sred), nsq = block_total(sn, sred), dsq = block_total(sd, sred);
+        const double keff_new = keff * (prod_new / prod_old);
+        const double dk = fabs(keff_new - keff);
+        if (it >= 1) keff = keff_new;                               // :1774
+        const double dphi = sqrt(dsq / nsq), norm = sqrt(nsq);
+        if (tid == 0) { A.hist[it] = keff; A.hist[A.max_outer + it] = dk; A.hist[2 * A.max_outer + it] = dphi; }
+        n_outer = it + 1;
+        if (!isfinite(keff_new) || !isfinite(dphi)) { status = 2; break; }
+        // normalise + Chebyshev (:1780-1788, src/solvers.cpp:720-756)
+        int mode = 0; double ca = 0.0, cb = 0.0;
+        if (it >= 2) {
+            if (cheb_it == 15) cheb_it = 0;
+            if (cheb_it == 0) mode = 1;
+            else if (cheb_it == 1) { mode = 2; ca = A.ca1; }
+            else { mode = 3; ca = A.a3[cheb_it]; cb = A.cb[cheb_it]; }
+            ++cheb_it;
+        }
+        const bool do_norm = norm > 1e-14;
+        for (long i = tid; i < NT; i += nt) {
+            double v = A.raw[i];
+            if (do_norm) v /= norm;
+            if (mode == 1) pa[i] = v;
+            else if (mode == 2) { const double a = pa[i]; v = a + ca * (v - a); pb[i] = v; }
+            else if (mode == 3) { const double a = pa[i], b = pb[i]; v = b + ca * (v - b) + cb * (b - a); pa[i] = v; }
+            A.phi[i] = v;
+        }
+        if (mode == 3) { double *t = pa; pa = pb; pb = t; }
+        __syncthreads();
+        if (dk < A.tol_keff && dphi < A.tol_flux) break;            // :1799-1802
+    }
+    if (tid == 0) { A.out->keff = keff; A.out->n_outer = n_outer; A.out->status = status; A.out->cg_total = cg_total; }
 }
 
 // adjoint helpers: sum over groups, weighted dot product, scaling

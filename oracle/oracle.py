@@ -192,10 +192,11 @@ class OracleNeutFEM:
         self._L.nfo_schur_apply(self._h, g, _dp(x), _dp(y))
         return y
 
-    def solve_group(self, g, rhs):
+    def solve_group(self, g, rhs, with_J=True):
+        """SchurSolver::Solve (src/solvers.cpp:203-240); with_J=False skips the J = -A^-1 B^T phi back-solve (:227-228)"""
         rhs = np.ascontiguousarray(rhs, dtype=np.float64)
-        phi = np.zeros(self.n_phi); J = np.zeros(self.n_J)
-        its = self._L.nfo_solve_group(self._h, g, _dp(rhs), _dp(phi), _dp(J))
+        phi = np.zeros(self.n_phi); J = np.zeros(self.n_J) if with_J else None
+        its = self._L.nfo_solve_group(self._h, g, _dp(rhs), _dp(phi), _dp(J) if with_J else None)
         return phi, J, its
 
     def diag_cache(self, g):

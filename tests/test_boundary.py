@@ -134,6 +134,9 @@ def test_vtk_export_without_gpu(tmp_path):
     assert vals[6 + 0 * 3 + 2] == 2.5 and sum(vals) == 11 + 2.5            # cell (iz=1, iy=0, ix=2)
     i = txt.index("SCALARS SigS_0_to_1 double 1"); assert float(txt[i + 2 + 3]) == 0.125     # cell (0,1,0)
     i = txt.index("SCALARS Flux_total double 1"); assert float(txt[i + 2]) == 2.0
+    # export_adjoint writes Flux_adj_g* only once SolveAdjoint has run (has_valid_adjoint_, src/NeutFEM.cpp:2206): never here
+    s.ExportVTK(base + "_a", export_flux=True, export_current=False, export_xs=False, export_adjoint=True)
+    assert "Flux_adj_g0" not in open(base + "_a.vtk").read()
     s.ExportFluxVTK(base + "_f"); s.ExportXSVTK(base + "_x")
     assert "SCALARS D_g0 double 1" not in open(base + "_f.vtk").read() and "Flux_g0" not in open(base + "_x.vtk").read()
     with pytest.raises(RuntimeError):

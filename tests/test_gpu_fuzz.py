@@ -38,7 +38,10 @@ def test_random_call_sequences(seed):
     log = []
     tolf = 1e-5                                                  # module default tol_flux = CG tolerance (src/NeutFEM.cpp:113-300)
     for step in range(7):
-        kthr, fthr = max(1e-9, 0.1 * tolf), max(1e-7, 5.0 * tolf)   # both sides stop on the same tests: agreement is tolerance-limited
+        # both sides stop on the same DISCRETE tests, so agreement is tolerance-limited: when a stop test sits on a knife edge the summation
+        # order of a dot product decides which side of it a run lands on, and one outer iteration more or less moves k by up to
+        # dk < tol_keff (seed 13: the oracle itself stops after 29 or 31 outers depending on the tolerances' last digits)
+        kthr, fthr = max(1e-9, 0.5 * tolf), max(1e-7, 5.0 * tolf)
         op = rnd.choice(["solve", "solve", "solve", "reset", "tol", "xs", "adjoint", "coarse"])
         log.append(op)
         if op == "solve":

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI, neutfem_amd.capi) against the CPU oracle on the same
 inputs.  Bars (BASELINE.json north_star): k-eff within 1 pcm, flux within 1e-8 relative L2.  The operator
 level is checked much tighter (1e-12) because it is the same arithmetic in a different summation order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -242,6 +244,20 @@ def test_pybind_module_end_to_end():
     assert fa.shape == (2, 38, 38) and np.isfinite(fa).all() and fa.max() > 0
     vol = np.outer(np.diff(inp["y_breaks"]), np.diff(inp["x_breaks"]))
     assert abs((phi * fa * vol).sum() - 1.0) < 1e-10                         # <phi, phi+> = 1 (src/NeutFEM.cpp:2020-2066)
+    # ExportVTK(export_adjoint=True) after SolveAdjoint: Flux_adj_g* fields hold the adjoint DOF-0 values (src/NeutFEM.cpp:2206-2214)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        m.ExportVTK(os.path.join(td, "adj"), export_flux=True, export_current=False, export_xs=False, export_adjoint=True)
+        txt = open(os.path.join(td, "adj.vtk")).read().split("\n")
+        for g in range(2):
+            i = txt.index(f"SCALARS Flux_adj_g{g} double 1")
+            vals = np.array([float(v) for v in txt[i + 2:i + 2 + 38 * 38]])
+            assert np.abs(vals - fa[g].ravel()).max() <= 1e-5 * np.abs(fa[g]).max()     # the file holds 6 significant digits
+        m.ExportFluxVTK(os.path.join(td, "adj2"), adjoint=True)
+        assert "Flux_adj_g1" in open(os.path.join(td, "adj2.vtk")).read()
+        m.reset_flux()                                                       # has_valid_adjoint_ = false (:347-354)
+        m.ExportVTK(os.path.join(td, "adj3"), True, False, False, True)
+        assert "Flux_adj_g0" not in open(os.path.join(td, "adj3.vtk")).read()
 
 
 def test_vtk_export_currents(tmp_path):

@@ -1,0 +1,87 @@
+"""The three execution shapes of the full-Schur SolveKeff -- (0) host-driven outer loop with the classic four-launch CG,
+(0') the same with the fused-direction two-launch CG (k_apply3), (2) the resident one-workgroup kernel (k_resident_keff) --
+run the same per-cell arithmetic and differ only in the summation order of the dot products.  They must agree with each
+other and with the oracle: tightly at tight tolerances, and with the same iteration counts on well-conditioned problems."""
+import numpy as np
+import pytest
+
+from helpers import TEST_TOL, degenerate_inputs, load_inputs, make_hip, make_oracle, rel_l2, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2)]
+
+
+def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
+    s = make_hip(inp, rt, p); s.set_tol(*tol)
+    for k, v in opts.items():
+        s.set_option(k, v)
+    k, n = s.solve_keff(coarse, factors)
+    out = dict(k=k, n=n, cg=s.history()["cg"].copy(), hk=s.history()["k"].copy(), phi=s.get_phi().copy(), path=s.info("last_path"), J=s.get_J().copy())
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("shape,rt,p,ng", [((24, 20, 6), 0, 0, 2), ((7, 6, 5), 0, 0, 3), ((19, 19, 1), 0, 0, 2), ((110, 1, 1), 1, 1, 2),
+                                            ((12, 10, 1), 1, 1, 2), ((9, 8, 7), 1, 1, 2), ((10, 9, 1), 2, 2, 1), ((8, 6, 5), 2, 1, 2),
+                                            ((16, 14, 1), 1, 0, 2), ((40, 33, 3), 0, 0, 2)])
+def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
+    inp = synthetic_inputs(*shape, ng=ng, seed=7)
+    tol = (1e-11, 1e-11, 1e-11, 1500, 3000)
+    o = make_oracle(inp, rt, p); o.set_tol(*tol); ko = o.SolveKeff()
+    res = {}
+    for name, opts, path in PATHS:
+        r = res[name] = _run(inp, rt, p, tol, opts)
+        assert r["path"] == path, (name, r["path"])
+        assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
+        assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
+        assert rel_l2(r["J"].ravel(), o.J_dofs().ravel()) < 1e-7, name
+    for name in ("fuse3", "resident"):
+        assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
+        assert rel_l2(res[name]["phi"], res["classic"]["phi"]) < 1e-9
+
+
+@pytest.mark.parametrize("name,rt", [("iaea2d", 0), ("koeberg2d", 0), ("koeberg2d", 1), ("iaea2d", 1), ("biblis2d", 0), ("zion2d", 0)])
+def test_paths_on_benchmarks_with_driver_settings(name, rt):
+    """the reference drivers' own settings (loose tolerances, coarse-mesh start): same outer and CG counts as the oracle on
+    every path, k-history to 1e-9 -- these problems are well conditioned, so the summation order does not move a stop test"""
+    inp = load_inputs(name); f = [int(v) for v in inp["coarse_factors"]]
+    o = make_oracle(inp, rt, rt); o.set_tol(*TEST_TOL); ko = o.SolveKeff(True, f); ho = o.history()
+    for pname, opts, path in PATHS:
+        r = _run(inp, rt, rt, TEST_TOL, opts, True, f)
+        assert r["path"] == path
+        assert r["n"] == ho["n_outer"], (pname, r["n"], ho["n_outer"])
+        assert np.array_equal(r["cg"], ho["cg"]), (pname, r["cg"].ravel(), ho["cg"].ravel())
+        np.testing.assert_allclose(r["hk"], ho["k"][:r["n"]], rtol=1e-9)
+        assert abs(r["k"] - ko) / ko < 1e-9
+        assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, pname
+
+
+def test_resident_path_limits_and_warm_start():
+    """the resident kernel takes over only below resident_max_dofs and only for the iterative full-Schur path; warm start, reset
+    and history behave like the host-driven loop"""
+    inp = load_inputs("iaea2d")
+    o = make_oracle(inp); s = make_hip(inp)
+    o.set_tol(*TEST_TOL); s.set_tol(*TEST_TOL)
+    k1, n1 = s.solve_keff(); assert s.info("last_path") == 2
+    ko1 = o.SolveKeff(); assert abs(k1 - ko1) / ko1 < 1e-9 and n1 == o.info("last_outer")
+    k2, n2 = s.solve_keff(); ko2 = o.SolveKeff()                    # warm start from the last k and flux (src/NeutFEM.cpp:1662)
+    assert abs(k2 - ko2) / ko2 < 1e-9 and n2 == o.info("last_outer") and n2 < n1
+    s.set_option("resident_max_dofs", 1000)
+    s.reset_flux(); k3, n3 = s.solve_keff(); assert s.info("last_path") == 0 and n3 == n1 and abs(k3 - k1) / k1 < 1e-9
+    s.set_option("resident_max_dofs", 5000)
+    s.reset_flux(); s.solve_keff(False, (), True); assert s.info("last_path") == 1      # diagonal path keeps its own device loop
+    s.set_tol(0.0, 1e-4, 1e-4, 3, 1000); s.reset_flux()
+    k4, n4 = s.solve_keff(); assert n4 == 3 and s.info("last_path") == 2 and len(s.history()["k"]) == 3
+    s.close()
+
+
+def test_resident_reports_divergence():
+    inp = synthetic_inputs(8, 6, 5, 2, seed=1)
+    from neutfem_amd.capi import HipSolver
+    s = HipSolver(0, 0, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"]); s.set_linear_solver(6)
+    s.upload_xs(inp["D"], inp["SigR"], 0.0 * inp["NSF"], inp["Chi"], inp["SigS"]); s.build()
+    with pytest.raises(RuntimeError, match="diverged"):            # no fission: prod_old = 0 -> k is NaN
+        s.solve_keff()
+    assert s.info("last_path") == 2
+    s.close()
