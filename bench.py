@@ -231,6 +231,12 @@ def main():
             per = a.loopback_slabs                                  # launches per timed pass (one per local slab)
             passes.append(dict(name=nm, kernel=kern[d], launches=c * per, avg_ms=ms / c / per,
                                alg_bytes=algorithmic_bytes(dim, Nl, nJd[d]) + (fused_bytes if d == 0 else 0.0)))
+    if not passes:
+        # small / medium meshes run the three passes of an apply as ONE launch (k_apply3): no per-direction timing exists; the
+        # dominant kernel is that launch, charged with the whole apply (+ the fused CG vector updates)
+        c, ms = s.profile("schur_apply")
+        passes.append(dict(name="schur_apply", kernel="k_apply3 (x, y, z passes of one Schur apply in one launch)", launches=max(c, 1), avg_ms=ms / max(c, 1),
+                           alg_bytes=24.0 * Nl + 40.0 * sum(nJd[d] for d in range(dim)) + fused_bytes))
     dom = max(passes, key=lambda p: p["avg_ms"])
     # HBM traffic of that kernel from the PMC counters.  Counters cannot be read inside this process: the figure comes from separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/collect.sh; gfx950 x2 read correction), stored per
@@ -242,7 +248,7 @@ def main():
             pj = json.load(f)
         pmc = pj["kernels"]
         import re
-        pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_s<\d+, 1,", "schur_z": r"k_schur_s<\d+, 2,"}[dom["name"]]
+        pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_s<\d+, 1,", "schur_z": r"k_schur_s<\d+, 2,", "schur_apply": r"k_apply3<"}[dom["name"]]
         hits = [k for k in pmc if re.match(pat, k)]
         key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None
         if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:

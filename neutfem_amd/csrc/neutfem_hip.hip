@@ -117,14 +117,17 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
-    int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID;
+    int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID, opt_sepfold = 1;
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
-    int opt_s_tx = 0, opt_s_seg = 0;                      // tuning overrides (nf_set_option)
+    int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
     int opt_fuse3 = 1; long fuse3_max_cells = 4L << 20;   // fused-direction CG (two launches per iteration) up to this many cells
-    int opt_resident = 1; long resident_max_dofs = 5000;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
+    int opt_resident = 1, opt_resident_lds = 1; long resident_max_dofs = 2500;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
+    long direct_max_dofs = 2048;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group
+    int last_direct = 0;                                  // the last solve used: 0 CG as configured, 1 dense S^-1, 2 CG to 1e-14 standing in
+    long standin_unconverged = 0;                         // group solves of the stand-in that ended above 1e-14
     // coarse twin of the team (SolveCoarse): built on the first coarse-mesh start and kept until the cross sections, the boundary
     // conditions or the team change -- creating and factoring it costs more than solving it on the benchmark meshes
     std::vector<nf_solver *> cc; int cc_f[3] = {0, 0, 0};
@@ -155,6 +158,7 @@ struct nf_solver {
     double *d_L[3] = {nullptr, nullptr, nullptr}, *d_DR[3] = {nullptr, nullptr, nullptr}, *d_D0[3] = {nullptr, nullptr, nullptr};
     long nlines[3] = {0, 0, 0};
     double *d_Sinv = nullptr;
+    double *d_Sdense = nullptr; bool dense_valid = false;   // explicit-S branch: S^-1 per group, ng * nphi^2, column-major
     // slab interfaces (partition method for the z lines), all per z-line
     double *d_alo = nullptr, *d_ahi = nullptr, *d_hlo = nullptr, *d_hhi = nullptr, *d_gfl = nullptr;   // ng * nlines[2]
     double *d_sinv_lo = nullptr, *d_sinv_hi = nullptr;  // ng * nlines[2]
@@ -168,6 +172,7 @@ struct nf_solver {
     bool raw_valid = false, raw_is_diag = false;
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
     CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
+    CgLean lean_z1 = { nullptr, nullptr, 0, 0, 0 };     // slab teams: the endpoint pass of the z lines consumes the all-reduced |r|^2
     double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nx*ny*(nz+1) (nf_get_J)
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
     bool cmfd_init = false; double cmfd_relax = 1.0;
@@ -417,7 +422,7 @@ int nf_destroy(nf_handle S)
     for (auto &p : S->d_SigS) dfree(p);
     for (auto &p : S->d_Ms) dfree(p);
     dfree(S->d_Ms_tab);
-    dfree(S->d_Cd); dfree(S->d_Mf); dfree(S->d_Mchi); dfree(S->d_phi_adj); dfree(S->d_Sinv);
+    dfree(S->d_Cd); dfree(S->d_Mf); dfree(S->d_Mchi); dfree(S->d_phi_adj); dfree(S->d_Sinv); dfree(S->d_Sdense);
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
@@ -529,7 +534,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("last_path", T->last_path); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
+    K("last_path", T->last_path); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
 #undef K
     return -1;
 }
@@ -537,7 +542,7 @@ long nf_info(nf_handle S, const char *key)
 int nf_set_bc(nf_handle S, int attr, int bc_type)
 {
     if (!S || attr < 0 || attr >= 8) return fail(NF_ERR_ARG, "nf_set_bc: bad attribute %d", attr);
-    S->bc_set[attr] = 1; S->bc_type[attr] = bc_type;
+    S->bc_set[attr] = 1; S->bc_type[attr] = bc_type; S->dense_valid = false;
     coarse_cache_drop(S->team);
     return NF_OK;
 }
@@ -550,7 +555,7 @@ int nf_upload_xs(nf_handle S, const double *D, const double *SigR, const double 
     const size_t NN = (size_t)S->N * S->ng, B = NN * sizeof(double);
     // the device copies are overwritten from here on: whatever was built from the old ones is stale until the next nf_build,
     // also when this upload is refused below (a refused upload leaves the handle un-built, never half-valid)
-    S->xs_uploaded = false; S->built = false; S->diag_valid = false; S->cmfd_init = false;
+    S->xs_uploaded = false; S->built = false; S->diag_valid = false; S->cmfd_init = false; S->dense_valid = false;
     coarse_cache_drop(S->team);
     NFCHK(dalloc(&S->d_D, NN)); NFCHK(dalloc(&S->d_SigR, NN)); NFCHK(dalloc(&S->d_NSF, NN)); NFCHK(dalloc(&S->d_Chi, NN));
     HIPCHK(hipMemcpyAsync(S->d_D, D, B, hipMemcpyHostToDevice, st));
@@ -649,7 +654,7 @@ int nf_build(nf_handle S)
     if (!S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NP * ng)); NFCHK(dalloc(&S->d_p1, (size_t)NP * ng)); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    S->built = true; S->diag_valid = false; S->cmfd_init = false;   // src/NeutFEM.cpp:454-456
+    S->built = true; S->diag_valid = false; S->cmfd_init = false; S->dense_valid = false;   // src/NeutFEM.cpp:454-456
     S->team->linked_ready = false;
     return NF_OK;
 }
@@ -785,6 +790,16 @@ static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int
     return NF_OK;
 }
 
+// lean CG on slab teams: process-local sum of the partials into red[0] (+ all-reduce over ranks); the kernels that consume the
+// total derive the CG scalars themselves (CgLean with count < 0), so no k_cg_logic launch follows
+static int team_reduce(nf_team *T, const std::vector<int> &counts, double *red)
+{
+    PartSegs ps = segs_for(T, counts);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, 1, T->d_cg, red, 0.0, 0, 1, red);
+    if (T->rccl_reduce) NCCLCHK(g_rccl.AllReduce(red, red, 1, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
+    return NF_OK;
+}
+
 // ---- Schur apply -----------------------------------------------------------------------------
 template <int NCH, int NB>
 static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int lpl_log2, int first, int last,
@@ -849,10 +864,11 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
-    sa.xcd = T->opt_xcd;
-    const size_t lds = (size_t)(4 * TX * NSEG + TX + 16) * sizeof(double);
+    sa.xcd = T->opt_xcd; sa.wsmin = T->opt_wsmin;
+    const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 16) * sizeof(double);
     const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
-#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz)
+    const CgLean lz = (zmode == 1 && S->nloc == 1 && fz.p) ? S->lean_z1 : CgLean{ nullptr, nullptr, 0, 0, 0 };
+#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
         else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
     if (zmode != 0) {
@@ -860,6 +876,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
         sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
         sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
         sa.jz = zmode == 3 ? S->d_Jz + (size_t)g * nl * (S->nz + 1) : nullptr;
+        if (zmode == 2 && T->sep_sweeps == 0 && T->opt_sepfold) {     // separators formed inside the pass (no k_separators launch)
+            sa.fold = 1; sa.rlo = S->d_rlo; sa.rhi = S->d_rhi; sa.sinv_lo = S->d_sinv_lo + g * nl; sa.sinv_hi = S->d_sinv_hi + g * nl;
+        }
         if (S->nb == 0) NF_S_SEG(2, true, 0); else if (S->nb == 1) NF_S_SEG(2, true, 1); else NF_S_SEG(2, true, 2);
     } else if (d == 1) {
         if (S->nb == 0) NF_S_SEG(1, false, 0); else if (S->nb == 1) NF_S_SEG(1, false, 1); else NF_S_SEG(1, false, 2);
@@ -875,7 +894,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
 // values (+ Jacobi sweeps for thin slabs).  The exchange and the separator kernels run on the comm stream; ev_xchg marks
 // their end -- the caller's z pass (or current reconstruction) waits for it, the x / y passes do not.
 static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double *> &xs, const std::vector<double *> &ys, const CgScalars *cg,
-                               hipEvent_t after_z1)
+                               hipEvent_t after_z1, bool need_u = false)
 {
     const int ns = (int)T->slabs.size();
     for (int i = 0; i < ns; ++i) {
@@ -893,9 +912,11 @@ static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double
             if (S->if_lo || S->if_hi) launch(S, S->nlines[2], dim3((unsigned)((S->nlines[2] * n_modes(S) + 255) / 256)));
         }
     };
-    each_slab([&](nf_solver *S, long nl, dim3 gr) {
-        hipLaunchKernelGGL(k_separators, gr, dim3(256), 0, T->comm_stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi, S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl,
-                           S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, nl * n_modes(S), S->if_lo, S->if_hi, cg); });
+    // thick slabs (no separator sweeps): the accumulation pass forms u = (c_below + c_above) S_red^-1 itself (SlabArgs::fold)
+    if (need_u || T->sep_sweeps > 0 || !T->opt_sepfold)
+        each_slab([&](nf_solver *S, long nl, dim3 gr) {
+            hipLaunchKernelGGL(k_separators, gr, dim3(256), 0, T->comm_stream, S->d_clo, S->d_chi, S->d_rlo, S->d_rhi, S->d_sinv_lo + g * nl, S->d_sinv_hi + g * nl,
+                               S->d_ulo, S->d_uhi, S->d_ctlo, S->d_cthi, nl, nl * n_modes(S), S->if_lo, S->if_hi, cg); });
     for (int sweep = 0; sweep < T->sep_sweeps; ++sweep) {
         each_slab([&](nf_solver *S, long nl, dim3 gr) {
             hipLaunchKernelGGL(k_sep_couple, gr, dim3(256), 0, T->comm_stream, S->d_gfl + g * nl, S->d_ulo, S->d_uhi, S->d_elo, S->d_ehi, nl, nl * n_modes(S), S->if_lo, S->if_hi, cg); });
@@ -1020,7 +1041,7 @@ static Fuse3Plan fuse3_plan(const nf_solver *S)
     P.A.nby = S->dim >= 2 ? P.A.gx[0] * P.A.gy[0] * modes : 0;
     P.A.nbz = S->dim == 3 ? P.A.gx[1] * P.A.gy[1] * modes : 0;
     P.nblocks = P.A.nbx + P.A.nby + P.A.nbz;
-    P.lds = (size_t)(4 * B + 64 + 16) * sizeof(double);
+    P.lds = (size_t)(4 * B + 320 + 16) * sizeof(double);
     P.A.stamps = nullptr;
 #ifdef NF_STAMPS
     { static long long *d_st = nullptr; if (!d_st) (void)hipMalloc((void **)&d_st, 48 * sizeof(long long)); P.A.stamps = d_st; g_stamps = d_st; }
@@ -1087,6 +1108,9 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     double *row1 = T->d_partials + T->partial_stride;
     const CgLean no_lean = { nullptr, nullptr, 0, 0, 0 };
     int rc = NF_OK;
+    // lean variant for slab teams (fused, RT0-P0): the endpoint pass of the z lines and k_cg_rupdate consume the all-reduced
+    // totals (d_red[1] = |r|^2, d_red[0] = p.q) and derive beta / alpha and the stop tests themselves: no k_cg_logic launches
+    const bool tlean = fused && T->opt_lean && !team_is_single(T);
     // fused-direction variant on top of the lean one (small / medium meshes): two launches per iteration, see k_apply3
     Fuse3Plan f3;
     nf_solver *S0 = T->slabs[0];
@@ -1115,8 +1139,21 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 continue;
             }
             if (lean) T->slabs[0]->lean = CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 };
+            if (tlean) for (auto *S : T->slabs) S->lean_z1 = CgLean{ T->d_cg, T->d_red + 1, -1, index & 1, index == 0 ? 1 : 0 };
             rc = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
             if (lean) T->slabs[0]->lean = no_lean;
+            if (tlean) {
+                for (auto *S : T->slabs) S->lean_z1 = no_lean;
+                if (rc == NF_OK) rc = team_reduce(T, acnt, T->d_red);
+                if (rc != NF_OK) break;
+                for (int i = 0; i < ns; ++i) {
+                    nf_solver *S = T->slabs[i];
+                    hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap,
+                                       CgLean{ T->d_cg, T->d_red, -1, index & 1, 0 });
+                }
+                rc = team_reduce(T, gcnt, T->d_red + 1);
+                continue;
+            }
             if (rc == NF_OK && !lean) rc = team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0);
             if (rc != NF_OK) break;
             for (int i = 0; i < ns; ++i) {
@@ -1138,6 +1175,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         launched += nb;
         // lean: the stop tests of the batch's last iteration have not been evaluated yet (the next x pass would do it)
         if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 });
+        if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 1, -1, launched & 1, 0 });
         if (hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream) != hipSuccess || hipStreamSynchronize(T->stream) != hipSuccess) {
             rc = fail(NF_ERR_HIP, "CG: reading the device scalars failed"); break;
         }
@@ -1277,7 +1315,7 @@ static int team_reconstruct_Jz(nf_team *T)
     std::vector<const double *> xs(ns); std::vector<double *> ys(ns);
     for (int g = 0; g < ng; ++g) {
         for (int i = 0; i < ns; ++i) { xs[i] = T->slabs[i]->d_raw + (size_t)g * T->slabs[i]->nphi; ys[i] = T->slabs[i]->d_q; }
-        NFCHK(team_endpoint_phase(T, g, xs, ys, nullptr, nullptr));
+        NFCHK(team_endpoint_phase(T, g, xs, ys, nullptr, nullptr, true));
         HIPCHK(hipStreamWaitEvent(T->stream, T->ev_xchg, 0));
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
@@ -1338,6 +1376,41 @@ static void cheb_tables(double *ca, double *cbv)
     const double sigma = CHEB_SIGMA, Gm = std::acosh(2. / sigma - 1.);
     ca[0] = cbv[0] = 0.; ca[1] = 2. / (2. - sigma); cbv[1] = 0.;
     for (int i = 2; i < CHEB_NMAX; ++i) { ca[i] = std::cosh((i - 1) * Gm) / std::cosh(i * Gm); cbv[i] = std::cosh((i - 2) * Gm) / std::cosh(i * Gm); }
+}
+
+// ---- explicit-S branch (src/solvers.cpp:114-124, 259-509) ----------------------------------------
+// FormSchurComplement + PrepareSolver once per BuildMatrices: column j of S = S e_j through the matrix-free apply (the
+// reference solves A x = B^T e_j and multiplies by B: the same numbers up to its 1e-14 drop threshold), then S^-1 by n
+// Gauss-Jordan steps on the whole chip.  Undivided meshes of at most direct_max_dofs unknowns per group.
+static int dense_prepare(nf_team *T)
+{
+    nf_solver *S = T->slabs[0];
+    if (S->dense_valid) return NF_OK;
+    const int n = (int)S->nphi, ng = S->ng; const size_t nn = (size_t)n * n;
+    hipStream_t st = T->stream;
+    NFCHK(dalloc(&S->d_Sdense, nn * ng));
+    DevTmp<double> work; NFCHK(dalloc(&work.p, nn));
+    for (int g = 0; g < ng; ++g) {
+        double *M = S->d_Sdense + (size_t)g * nn;
+        for (int j = 0; j < n; ++j) {
+            hipLaunchKernelGGL(k_unit_vector, dim3(grid_for(n)), dim3(256), 0, st, S->d_p, (long)n, (long)j);
+            NFCHK(team_schur_apply(T, g, { S->d_p }, { M + (size_t)j * n }, false, nullptr, nullptr));
+        }
+        double *a = M, *b = work.p;
+        const unsigned gr = (unsigned)((nn + 255) / 256);
+        for (int k = 0; k < n; ++k) { hipLaunchKernelGGL(k_gj_step, dim3(gr), dim3(256), 0, st, (const double *)a, b, n, k); std::swap(a, b); }
+        if (a != M) HIPCHK(hipMemcpyAsync(M, a, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    HIPCHK(hipGetLastError());
+    S->dense_valid = true;
+    return NF_OK;
+}
+static void dense_solve(nf_team *T, int g, const double *rhs, double *sol)
+{
+    nf_solver *S = T->slabs[0];
+    const int n = (int)S->nphi;
+    hipLaunchKernelGGL(k_dense_matvec, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, T->stream, (const double *)(S->d_Sdense + (size_t)g * n * n), rhs, sol, n);
 }
 
 // ---- SolveCoarse (src/NeutFEM.cpp:2380-2611) ---------------------------------------------------
@@ -1418,9 +1491,9 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     if (CT) {
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
-        CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
-        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->resident_max_dofs = T->resident_max_dofs;
-        CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev;
+        CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->resident_max_dofs = T->resident_max_dofs;
+        CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
     double kc = 1.0; int nout = 0;
     if (rc == NF_OK) {
@@ -1703,8 +1776,25 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     if (!T->d_rout) NFCHK(dalloc(&T->d_rout, 1));
     A.hist = T->d_hist; A.hist_cg = T->d_hist_cg; A.out = T->d_rout;
     // the kernel indexes its history with max_outer as the row length
-    const int B = 512; const size_t lds = (size_t)(5 * B + 64 + 16) * sizeof(double);
-#define NF_RES(VECV, NBV) hipLaunchKernelGGL((k_resident_keff<VECV, NBV>), dim3(1), dim3(B), lds, st, A)
+    const int B = 512;
+    // LDS plan: 160 KiB per workgroup; behind the scratch of the direction passes the CG vectors and this group's factors, in
+    // priority order, as far as they fit (ResidentArgs::lds_mask)
+    A.Cd0 = S->d_Cd; A.lds_mask = 0;
+    long used = 5 * B + 64 + 16;
+    if (T->opt_resident_lds) {
+        const long cap = 160 * 1024 / 8 - 32;
+        const long NP2 = (S->nphi + 1) & ~1L, N2 = (S->N + 1) & ~1L;
+        const int bits[11] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10 };
+        for (int b : bits) {
+            if ((b == 6 || b == 7) && S->dim < 2) continue;
+            if ((b == 8 || b == 9) && S->dim < 3) continue;
+            const long need = (b <= 3 || b == 10) ? NP2 : N2;
+            if (used + need <= cap) { used += need; A.lds_mask |= 1 << b; }
+        }
+    }
+    const size_t lds = (size_t)used * sizeof(double);
+#define NF_RES(VECV, NBV) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<VECV, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_resident_keff<VECV, NBV>), dim3(1), dim3(B), lds, st, A); } while (0)
     const bool vec = S->nx % 2 == 0;
     if (S->nb == 0) { if (vec) NF_RES(true, 0); else NF_RES(false, 0); }
     else if (S->nb == 1) { if (vec) NF_RES(true, 1); else NF_RES(false, 1); }
@@ -1754,9 +1844,15 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     }
     long Ntot = 0; for (auto *S : T->slabs) Ntot += S->nphi;
     // SchurSolver type: DIRECT_* or n_phi < 200 -> "exact" solve (CG to 1e-14 stands in)
+    // SchurSolver::NeedsExplicitSchur (src/solvers.cpp:114-124): direct types, a type that was never pushed (quirk 11), n_phi < 200.
+    // Undivided meshes up to direct_max_dofs get the real thing (dense S^-1, dense_prepare); beyond that and on slab teams CG to
+    // 1e-14 stands in, bounded so that an ill-conditioned S (IAEA-3D: cond ~1e17) cannot run away; such solves are counted.
     const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (single && Ntot < 200);
+    const bool dense = direct && single && !T->rccl_reduce && Ntot <= T->direct_max_dofs;
     const double cg_tol = direct ? 1e-14 : o->tol_flux;           // SetTolerance forwards tol_flux (:334)
-    const int cg_max = direct ? (int)std::min<long>(20 * Ntot + 50, 2000000000L) : o->max_inner;   // CG ends in <= n steps in exact arithmetic
+    const int cg_max = direct ? (int)std::min<long>(20 * Ntot + 50, 200000L) : o->max_inner;   // CG ends in <= n steps in exact arithmetic
+    T->last_direct = dense ? 1 : direct ? 2 : 0;
+    if (dense) NFCHK(dense_prepare(T));
     // ChebyshevAccel(15, 0.98), src/solvers.cpp:664-700
     const int nmax = CHEB_NMAX; const double sigma = CHEB_SIGMA;
     double ca[16], cbv[16];
@@ -1810,8 +1906,13 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
                                    use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, NP, N);
                 rhs[i] = S->d_rhs; sol[i] = S->d_raw + g * NP;
             }
-            int its = 0;
-            if (!use_diag) NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr));
+            int its = 0; double res = 0.0;
+            if (use_diag) { }
+            else if (dense) { dense_solve(T, g, rhs[0], sol[0]); its = 1; }          // last_iterations_ = 1 (src/solvers.cpp:447)
+            else {
+                NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, &res));
+                if (direct && !(res <= 1e-14)) ++T->standin_unconverged;
+            }
             T->hist_cg.push_back(its); T->last_cg_total += its;
         }
         if (use_cmfd && it >= 2) NFCHK(cmfd_step(S0, keff, use_diag));   // :1750-1761
@@ -1907,8 +2008,10 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
         hipLaunchKernelGGL(k_sum_groups, dim3(grid_for(X->N)), dim3(256), 0, st, X->d_NSF, nsft[i].p, X->N, ng);    // :1898-1905
     }
     const bool direct = !o->solver_type_pushed || o->solver_type <= 2 || (team_is_single(T) && NPtot < 200);
+    const bool dense = direct && team_is_single(T) && !T->rccl_reduce && NPtot <= T->direct_max_dofs;   // S is symmetric: the same S^-1
     const double cg_tol = direct ? 1e-14 : o->tol_flux;
-    const int cg_max = direct ? (int)std::min<long>(20 * NPtot + 50, 2000000000L) : o->max_inner;
+    const int cg_max = direct ? (int)std::min<long>(20 * NPtot + 50, 200000L) : o->max_inner;
+    if (dense) NFCHK(dense_prepare(T));
     const int nmax = CHEB_NMAX; const double sigma = CHEB_SIGMA;
     double ca[16], cbv[16];
     cheb_tables(ca, cbv);
@@ -1938,7 +2041,8 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
                 rhs[i] = X->d_rhs; sol[i] = X->d_raw + g * X->nphi;
             }
             int its = 0;
-            rc = cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr);
+            if (dense) { dense_solve(T, g, rhs[0], sol[0]); its = 1; }
+            else rc = cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, nullptr);
             T->hist_cg.push_back(its); T->last_cg_total += its;
         }
         if (rc != NF_OK) break;
@@ -2118,14 +2222,18 @@ int nf_set_option(nf_handle S, const char *key, long value)
         T->opt_s_seg = (int)value;
     }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
+    else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
     else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
     else if (!strcmp(key, "cg_lean")) T->opt_lean = value != 0;
+    else if (!strcmp(key, "sep_fold")) T->opt_sepfold = value != 0;
     else if (!strcmp(key, "cg_lean_max_cells")) T->lean_max_cells = value;
     else if (!strcmp(key, "resident")) T->opt_resident = value != 0;
+    else if (!strcmp(key, "resident_lds")) T->opt_resident_lds = value != 0;
     else if (!strcmp(key, "resident_max_dofs")) T->resident_max_dofs = value;
+    else if (!strcmp(key, "direct_max_dofs")) T->direct_max_dofs = std::max(0L, std::min(8192L, value));
     else if (!strcmp(key, "cg_fuse3")) T->opt_fuse3 = value != 0;
     else if (!strcmp(key, "cg_fuse3_max_cells")) T->fuse3_max_cells = value;
     else if (!strcmp(key, "cg_lean_grid")) T->opt_lean_grid = (int)std::max(1L, std::min(1024L, value));

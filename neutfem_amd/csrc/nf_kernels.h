@@ -130,7 +130,13 @@ __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgSca
 // the iteration (CgScalars::rr2 / its2); `done` is sticky and every block derives the same stop decision on its own.
 // k_cg_lean_rr applies the FIN_RR step alone (idempotent: same inputs, same parity slot) so that the host, which reads the
 // scalars at the end of a batch, sees the outcome of the batch's last iteration.
+__device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred);
+// count < 0: partials[0] already holds the total (slab teams: k_finalize with reduce_only + the all-reduce over ranks put it there)
 struct CgLean { CgScalars *st; const double *partials; int count; int par; int first; };
+__device__ __forceinline__ double lean_total(const CgLean &lean, double *sred)
+{
+    return lean.count < 0 ? lean.partials[0] : strided_total(lean.partials, lean.count, sred);
+}
 __device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred)   // blocks of >= 256 threads; result in every thread
 {
     // summed by the first 256 threads only, so that blocks of any size (and k_finalize) produce the same bits: the other
@@ -149,7 +155,7 @@ __device__ __forceinline__ bool lean_rr_step(const CgLean &lean, bool writer, do
 {
     CgScalars *st = lean.st;
     const int q = lean.par, qo = q ^ 1;
-    const double rr_new = strided_total(lean.partials, lean.count, sred);
+    const double rr_new = lean_total(lean, sred);
     const double rr_old = st->rr2[qo];
     const int its_new = st->its2[qo] + 1;
     const bool conv = rr_new < st->tol_sq;
@@ -644,6 +650,11 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
 // unknowns themselves, negated: the z currents of the slab (current reconstruction on decomposed meshes).
 struct SlabArgs {
     int if_lo, if_hi, mode, xcd;
+    // fold = 1 (mode 2, no separator sweeps): the separator values are formed here from the exchanged planes instead of by
+    // k_separators -- u_lo = (r_lo + c_lo) S_red^-1, u_hi = (c_hi + r_hi) S_red^-1, the same expressions in the same order on
+    // both sides of an interface, so the two copies agree bitwise
+    int fold; const double *rlo, *rhi, *sinv_lo, *sinv_hi;
+    int wsmin;                                // segments from which the wavefront scan of the summaries replaces the serial loops (0: default 64)
     const double *alo, *ahi, *ulo, *uhi;      // per line
     double *clo, *chi;                        // per line (mode 1 outputs)
     double *jz;                               // mode 3: J = -u on the slab's own z faces [(face) * nx * ny + line] (Sol_J_, src/solvers.cpp:228)
@@ -662,9 +673,18 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
-    double *sA = sm, *sB = sm + T, *sA2 = sm + 2 * T, *sB2 = sm + 3 * T, *sZ0 = sm + 4 * T;
+    // Segment summaries: every thread composes the maps before (after) its own serially from LDS.  From 64 segments on (lines of
+    // >= 505 cells) whole wavefronts scan the summaries of a column with cross-lane shuffles instead (lane = segment, log2 steps)
+    // and hand every thread its incoming value through LDS: one more barrier per sweep, which only pays for the longest loops
+    // (measured on one box, s_wsmin: 512-cell lines 77 -> 72 us, but 256-cell lines 134 -> 141 us, 384-cell 513 -> 540 us, 128-cell
+    // 59 -> 66 us).  Needs full, aligned wavefronts.
+    const bool wscan = NSEG >= (sa.wsmin > 0 ? sa.wsmin : 64) && (T & 63) == 0;
+    const int NSP = wscan ? (NSEG | 1) : NSEG;                   // odd row length: conflict-free column-major rows
+    const int TP = wscan ? TX * NSP : T;
+    double *sA = sm, *sB = sm + TP, *sA2 = sm + 2 * TP, *sB2 = sm + 3 * TP, *sZ0 = sm + 4 * TP;
     act = act && tid < T;
     const int ixl = act ? tid % TX : 0, seg = act ? tid / TX : 0;
+    const int si = wscan ? ixl * NSP + seg : seg * TX + ixl;     // this thread's slot in the summary arrays
     const int ix = bx * TX + ixl;
     const bool valid = act && ix < nx;
     long base = (long)by * outer_stride + ix;
@@ -692,7 +712,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
                     xe_lo = x_before + ma.eL[0] * g1 + (NB > 1 ? ma.eL[1] * g2 : 0.0);            // xL: towards the separator below
                     x_before = x_before - ma.eR[0] * g1 - (NB > 1 ? ma.eR[1] * g2 : 0.0);          // xR: towards the chain
                 }
-                if (sa.mode >= 2) { u_lo = sa.ulo[lm]; x_before -= a_lo * u_lo; }
+                if (sa.mode >= 2) { u_lo = sa.fold ? (sa.rlo[lm] + sa.clo[lm]) * sa.sinv_lo[lineid] : sa.ulo[lm]; x_before -= a_lo * u_lo; }
             }
             if (sa.if_hi) {
                 a_hi = sa.ahi[lineid]; x_after = x[edge_hi];
@@ -703,7 +723,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
                     xe_hi = x_after - ma.eR[0] * g1 - (NB > 1 ? ma.eR[1] * g2 : 0.0);             // xR: towards the separator above
                     x_after = x_after + ma.eL[0] * g1 + (NB > 1 ? ma.eL[1] * g2 : 0.0);           // xL: towards the chain
                 }
-                if (sa.mode >= 2) { u_hi = sa.uhi[lm]; x_after += a_hi * u_hi; }
+                if (sa.mode >= 2) { u_hi = sa.fold ? (sa.chi[lm] + sa.rhi[lm]) * sa.sinv_hi[lineid] : sa.uhi[lm]; x_after += a_hi * u_hi; }
             }
         }
     }
@@ -763,17 +783,34 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 #pragma unroll
     for (int i = 0; i < SEG; ++i) { const double ti = NB == 0 ? xv[i] - xv[i + 1] : t[NB > 0 ? i : 0]; lz = ti - Lv[i] * lz; P = -Lv[i] * P; }
     NF_STAMP(stamp, 4);
-    if (act) { sA[seg * TX + ixl] = P; sB[seg * TX + ixl] = lz; }
+    if (act) { sA[si] = P; sB[si] = lz; }
     if (act && seg == 0) sZ0[ixl] = x_before - xL0;
     __syncthreads();
     NF_STAMP(stamp, 5);
+    if (wscan) {
+        // forward: incoming value of segment s = (f_{s-1} o ... o f_0)(z0); inclusive Hillis-Steele over the lanes of a column
+        int W = 16; while (W < NSEG) W <<= 1;
+        const int lane = tid & 63, cw = 64 / W, s_ = lane & (W - 1);
+        if (tid < T)
+            for (int c = (tid >> 6) * cw + lane / W; c < TX; c += (T >> 6) * cw) {
+                double A = s_ < NSEG ? sA[c * NSP + s_] : 1.0, B = s_ < NSEG ? sB[c * NSP + s_] : 0.0;
+                for (int d = 1; d < W; d <<= 1) {
+                    const double Ap = __shfl_up(A, d, W), Bp = __shfl_up(B, d, W);
+                    if (s_ >= d) { B = A * Bp + B; A = A * Ap; }
+                }
+                const double Ae = __shfl_up(A, 1, W), Be = __shfl_up(B, 1, W), z0 = sZ0[c];
+                if (s_ < NSEG) sB[c * NSP + s_] = s_ == 0 ? z0 : Ae * z0 + Be;
+            }
+        __syncthreads();
+    }
     if (SLAB && fuse && valid) {                                 // every read of the old p in this block is behind the barrier
 #pragma unroll
         for (int i = 0; i < SEG; ++i) if (c0 + i < n) fz.p[base + (long)(c0 + i) * sl] = xv[i];
         if (seg == 0) { if (sa.if_lo) fz.p[edge_lo] = xe_lo; if (sa.if_hi) fz.p[edge_hi] = xe_hi; }
     }
-    double z = sZ0[ixl];
-    for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
+    double z;
+    if (wscan) z = sB[si];
+    else { z = sZ0[ixl]; for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl]; }
     const double zin = z;
     double w[SEG];
 #pragma unroll
@@ -781,7 +818,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     double Q = 1.0, lu = 0.0;
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
-    if (act) { sA2[seg * TX + ixl] = Q; sB2[seg * TX + ixl] = lu; }
+    if (act) { sA2[si] = Q; sB2[si] = lu; }
     // y is only needed by the output stage: issue its loads here so they fly during the barrier + backward scan
 #pragma unroll
     for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (acc && valid && c < n && wr) ? y[base + (long)c * sl] : 0.0; }
@@ -789,7 +826,23 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     __syncthreads();
     NF_STAMP(stamp, 7);
     double u = 0.0;
-    if (act) for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];
+    if (wscan) {
+        // backward: incoming value of segment s = (f_{s+1} o ... o f_{NSEG-1})(0) = the B part of the suffix composition at s + 1
+        int W = 16; while (W < NSEG) W <<= 1;
+        const int lane = tid & 63, cw = 64 / W, s_ = lane & (W - 1);
+        if (tid < T)
+            for (int c = (tid >> 6) * cw + lane / W; c < TX; c += (T >> 6) * cw) {
+                double A = s_ < NSEG ? sA2[c * NSP + s_] : 1.0, B = s_ < NSEG ? sB2[c * NSP + s_] : 0.0;
+                for (int d = 1; d < W; d <<= 1) {
+                    const double Ap = __shfl_down(A, d, W), Bp = __shfl_down(B, d, W);
+                    if (s_ + d < W) { B = A * Bp + B; A = A * Ap; }
+                }
+                const double Bn = __shfl_down(B, 1, W);
+                if (s_ < NSEG) sA2[c * NSP + s_] = s_ == W - 1 ? 0.0 : Bn;
+            }
+        __syncthreads();
+        if (act) u = sA2[si];
+    } else if (act) for (int s = NSEG - 1; s > seg; --s) u = sA2[s * TX + ixl] * u + sB2[s * TX + ixl];
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { u = w[i] - Lv[i + 1] * u; w[i] = u; }
     const double ulo = zin * dinv_s - Lv[0] * w[0];             // u at the lower face of this segment
@@ -838,7 +891,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             const double a_lo = sa.alo[lineid];
             if (sa.mode == 1) sa.clo[lm] = -(NB == 0 ? x[edge_lo] : xe_lo) - a_lo * ulo;
             else {
-                const double u_lo = sa.ulo[lm];
+                const double u_lo = sa.fold ? (sa.rlo[lm] + sa.clo[lm]) * sa.sinv_lo[lineid] : sa.ulo[lm];
                 const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv;
                 if (NB > 0) {                                    // bubbles of the edge cell: faces (separator, first chain face)
                     const double ice = ma.D[edge_lo] / geom_factor(G, DIR, ix, (int)by, 0);
@@ -859,7 +912,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             const double a_hi = sa.ahi[lineid];
             if (sa.mode == 1) sa.chi[lm] = (NB == 0 ? x[edge_hi] : xe_hi) - a_hi * ulast;
             else {
-                const double u_hi = sa.uhi[lm];
+                const double u_hi = sa.fold ? (sa.chi[lm] + sa.rhi[lm]) * sa.sinv_hi[lineid] : sa.uhi[lm];
                 const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv;
                 if (NB > 0) {                                    // faces (last chain face, separator)
                     const int fsz = sa.if_lo ? 1 : 0;
@@ -881,15 +934,21 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 template <int SEG, int DIR, bool SLAB, int NB>
 __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
-                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz)
+                          int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz, CgLean lean)
 {
     extern __shared__ double sm[];
     if (cg && cg->done) return;
     const ModeArgs ma = select_mode(ma0, mt, blockIdx.z, NB + 1);
     // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
-    // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread
-    const bool fuse = SLAB && NB == 0 && sa.mode == 1 && fz.p != nullptr && cg->its > 0;
-    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? cg->beta : 0.0;
+    // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread.
+    // With lean.st it is also the consumer of the all-reduced |r|^2 (FIN_RR: beta, stop tests), like the x pass of an undivided mesh.
+    bool fuse = SLAB && NB == 0 && sa.mode == 1 && fz.p != nullptr && (lean.st ? !lean.first : cg->its > 0);
+    double f_beta = fuse && !lean.st ? cg->beta : 0.0;
+    if (SLAB && lean.st && !lean.first) {
+        double *sred_l = sm + 4 * TX * (NSEG + 1) + TX;
+        if (lean_rr_step(lean, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0, sred_l, &f_beta)) return;
+    }
+    const double f_alpha = fuse ? cg->alpha : 0.0;
     // XCD-aware tile order (experiment, sa.xcd): hardware deals consecutive workgroups round-robin to the 8 XCDs; remap so that
     // each XCD works on one contiguous range of tiles
     unsigned bx = blockIdx.x, by = blockIdx.y;
@@ -901,7 +960,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
                                                         (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
     if (SLAB && sa.mode == 3) return;
     if (last && partials) {
-        double *sred = sm + 4 * TX * NSEG + TX;
+        double *sred = sm + 4 * TX * (NSEG + 1) + TX;
         const double s = block_sum(dot, sred);
         if (threadIdx.x == 0) partials[((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx] = s;
     }
@@ -932,7 +991,7 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
                                                 const CgScalars *__restrict__ cg, CgFuse fz, CgLean lean)
 {
     extern __shared__ double sm[];
-    double *sred = sm + 4 * (int)blockDim.x + 64;                // behind the largest tile's scan arrays (4 T + TX doubles, T <= blockDim, TX <= 64)
+    double *sred = sm + 4 * (int)blockDim.x + 320;               // behind the largest tile's scan arrays (<= 4 TX (NSEG+1) + TX doubles, TX NSEG <= blockDim, TX <= 64)
     long long *stamp = nullptr;
 #ifdef NF_STAMPS
     if (A.stamps && threadIdx.x == 0) {
@@ -966,7 +1025,7 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
         const int r = b < (unsigned)(A.nbx + A.nby) ? 0 : 1;
         const unsigned t = b - A.nbx - (r ? A.nby : 0);
         const unsigned bx = t % A.gx[r], by = (t / A.gx[r]) % A.gy[r], bz = t / (A.gx[r] * A.gy[r]);
-        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = 0; sa.alo = sa.ahi = sa.ulo = sa.uhi = nullptr; sa.clo = sa.chi = sa.jz = nullptr;
+        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = sa.wsmin = sa.fold = 0; sa.alo = sa.ahi = sa.ulo = sa.uhi = sa.rlo = sa.rhi = sa.sinv_lo = sa.sinv_hi = nullptr; sa.clo = sa.chi = sa.jz = nullptr;
         if (r == 0) {
             const ModeArgs ma = select_mode(may0, mty, bz, NB + 1);
             dot = schur_s_tile<SEG, 1, false, NB>(ma, G, Ly, DRy, D0y, A.n[0], A.sl[0], A.ostride[0], nx, A.TX[0], A.NSEG[0], bx, by, bz, A.gy[0],
@@ -1048,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_cg_rupdate(double *__restrict__ r, cons
     if (cg->done) return;
     double alpha;
     if (lean.st) {                                              // lean CG: this kernel consumes the p.q partials (FIN_PAP)
-        const double pq = strided_total(lean.partials, lean.count, sred);
+        const double pq = lean_total(lean, sred);
         const bool brk = fabs(pq) < 1e-30;
         alpha = brk ? 0.0 : lean.st->rr2[lean.par] / pq;
         if (blockIdx.x == 0 && threadIdx.x == 0) { lean.st->pAp = pq; lean.st->pend = 0; if (brk) lean.st->done = 1; else lean.st->alpha = alpha; }
@@ -1287,6 +1346,9 @@ struct ResidentArgs {
     double keff0, tol_keff, tol_flux, cg_tol; int cg_max, max_outer;
     double ca1, a3[16], cb[16];
     double *hist; int *hist_cg; ResidentOut *out;
+    // LDS residency (host plan, greedy by priority): bit 0 p, 1 q, 2 r, 3 x_sol, 4+2d L[d], 5+2d DR[d], 10 C diagonal.  One CU
+    // moves ~10 B/cycle to and from L2 but 128 B/cycle to and from LDS, and a barrier no longer waits for global store acks.
+    const double *Cd0; int lds_mask;
 };
 __device__ __forceinline__ double block_total(double v, double *sred)     // fixed-order sum over the block, result in every thread
 {
@@ -1299,14 +1361,14 @@ __device__ __forceinline__ double block_total(double v, double *sred)     // fix
 }
 // all tiles of one y / z pass, nconc = blockDim / (TX NSEG) of them side by side; every thread runs every round (barriers inside)
 template <int SEG, int DIR, int NB>
-__device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, const ModeArgs &mad, int g, double *sm, const SlabArgs &sa0, const CgFuse &fz)
+__device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, const ModeArgs &mad, const double *Ld, const double *DRd, int g, double *sm,
+                                                  const SlabArgs &sa0, const CgFuse &fz)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int T = A.TX[r] * A.NSEG[r];
     const int nconc = nt / T, slot = tid / T, ltid = tid - slot * T;
     const int ntiles = A.gx[r] * A.gy[r] * A.nmodes;
-    double *smt = sm + (slot < nconc ? slot : 0) * (4 * T + A.TX[r]);
-    const long N = A.N;
+    double *smt = sm + (slot < nconc ? slot : 0) * (4 * T + (A.NSEG[r] >= 64 ? 5 : 1) * A.TX[r]);   // padded rows when the wavefront scan is on
     double dot = 0.0;
     for (int t0 = 0; t0 < ntiles; t0 += nconc) {
         const int t = t0 + slot;
@@ -1314,7 +1376,7 @@ __device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, 
         const unsigned tt = act ? t : 0;
         const unsigned bx = tt % A.gx[r], by = (tt / A.gx[r]) % A.gy[r], bz = tt / (A.gx[r] * A.gy[r]);
         const ModeArgs ma = select_mode(mad, A.mt[DIR], bz, NB + 1);
-        dot += schur_s_tile<SEG, DIR, false, NB>(ma, A.G, A.L[DIR] + g * N, A.DR[DIR] + g * N, A.D0[DIR] + g * A.nlines[DIR], A.n[r], A.sl[r], A.ostride[r],
+        dot += schur_s_tile<SEG, DIR, false, NB>(ma, A.G, Ld, DRd, A.D0[DIR] + g * A.nlines[DIR], A.n[r], A.sl[r], A.ostride[r],
                                                  A.G.nx, A.TX[r], A.NSEG[r], bx, by, bz, A.gy[r], ltid, act, smt, sa0, fz, false, false, 0.0, 0.0, true);
         __syncthreads();                                         // the tile's scan arrays are reused by the next round
     }
@@ -1328,7 +1390,17 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
     double *sred = sm + 5 * (int)blockDim.x + 64;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
     const int ng = A.ng; const long N = A.N, NP = A.nphi, NT = NP * ng;
-    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = nullptr; sa0.clo = sa0.chi = sa0.jz = nullptr;
+    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = nullptr;
+    // vectors and factors that fit are kept in LDS behind the scratch area (ResidentArgs::lds_mask); the rest stays in global memory
+    double *lds = sm + 5 * (int)blockDim.x + 64 + 16;
+    long lo = 0;
+    auto carve = [&](int bit, long n) -> double * { if (!((A.lds_mask >> bit) & 1)) return nullptr; double *q_ = lds + lo; lo += (n + 1) & ~1L; return q_; };
+    double *vp = carve(0, NP), *vq = carve(1, NP), *vr = carve(2, NP), *vx = carve(3, NP);
+    double *fL[3], *fR[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { fL[d] = carve(4 + 2 * d, N); fR[d] = carve(5 + 2 * d, N); }
+    double *fC = carve(10, NP);
+    double *const wp = vp ? vp : A.p, *const wq = vq ? vq : A.q, *const wr = vr ? vr : A.r;
     double keff = A.keff0;
     int cheb_it = 0, n_outer = 0, status = 0, cg_total = 0;
     double *pa = A.p0, *pb = A.p1;
@@ -1343,7 +1415,15 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
         const double prod_old = block_total(s, sred);
         const double inv_k = 1.0 / keff;
         for (int g = 0; g < ng; ++g) {
-            double *xsol = A.raw + (long)g * NP;
+            double *const graw = A.raw + (long)g * NP;
+            double *const xsol = vx ? vx : graw;
+            // this group's line factors and C diagonal into LDS (when planned)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (fL[d]) for (long i = tid; i < N; i += nt) fL[d][i] = A.L[d][g * N + i];
+                if (fR[d]) for (long i = tid; i < N; i += nt) fR[d][i] = A.DR[d][g * N + i];
+            }
+            if (fC) for (long i = tid; i < NP; i += nt) fC[i] = A.Cd0[g * NP + i];
             // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
             s = 0.0;
             for (long i = tid; i < NP; i += nt) {
@@ -1355,15 +1435,24 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                     if (gp == g || !M) continue;
                     v += M[i] * (gp < g ? A.raw : A.phi)[gp * NP + i];
                 }
-                xsol[i] = 0.0; A.r[i] = v; A.p[i] = v; s += v * v;
+                xsol[i] = 0.0; wr[i] = v; wp[i] = v; s += v * v;
             }
             double rr = block_total(s, sred);
             const double rhs_norm = sqrt(rr), tol_sq = A.cg_tol * A.cg_tol * rhs_norm * rhs_norm;
             int its = 0, pend = 0; double alpha = 0.0, beta = 0.0;
-            const CgFuse fz = { A.p, A.r, xsol, nullptr };
+            const CgFuse fz = { wp, wr, xsol, nullptr };
             ModeArgs mad[3];
+            const double *dL[3], *dR[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { mad[d] = A.ma[d]; mad[d].D += g * N; for (int q = 0; q <= NB; ++q) mad[d].Cd[q] += g * NP; }
+            for (int d = 0; d < 3; ++d) {
+                mad[d] = A.ma[d]; mad[d].D += g * N;
+                for (int q = 0; q <= NB; ++q) {
+                    const long off = A.ma[d].x[q] - A.p;         // offset of this moment inside a flux vector
+                    mad[d].x[q] = wp + off; mad[d].y[q] = wq + off;
+                    mad[d].Cd[q] = fC ? fC + off : A.Cd0 + g * NP + off;
+                }
+                dL[d] = fL[d] ? fL[d] : A.L[d] + g * N; dR[d] = fR[d] ? fR[d] : A.DR[d] + g * N;
+            }
             while (its < A.cg_max) {
                 const bool fuse = its > 0;
                 double dot = 0.0;
@@ -1374,26 +1463,28 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                     const bool active = gt < ntask;
                     const int mode = active ? gt / A.ntask_x : 0;
                     const ModeArgs ma = select_mode(mad[0], A.mt[0], mode, NB + 1);
-                    const double dx = schur_x_task<2, 1, VEC, NB>(ma, A.G, A.L[0] + g * N, A.DR[0] + g * N, A.D0[0] + g * A.nlines[0], A.G.nx, A.G.ny,
+                    const double dx = schur_x_task<2, 1, VEC, NB>(ma, A.G, dL[0], dR[0], A.D0[0] + g * A.nlines[0], A.G.nx, A.G.ny,
                                                                   A.nlines[0], A.lpl_log2, 1, gt % A.ntask_x, tid & 63, active, fuse, alpha, beta, fz);
                     if (A.dim == 1) dot += dx;
                 }
                 __syncthreads();
                 // ---- y, then z lines: accumulate into q; the last direction also gives p.q
-                if (A.dim >= 2) { const double ds = resident_s_pass<SEG, 1, NB>(A, 0, mad[1], g, sm, sa0, fz); if (A.dim == 2) dot += ds; }
-                if (A.dim == 3) dot += resident_s_pass<SEG, 2, NB>(A, 1, mad[2], g, sm, sa0, fz);
+                if (A.dim >= 2) { const double ds = resident_s_pass<SEG, 1, NB>(A, 0, mad[1], dL[1], dR[1], g, sm, sa0, fz); if (A.dim == 2) dot += ds; }
+                if (A.dim == 3) dot += resident_s_pass<SEG, 2, NB>(A, 1, mad[2], dL[2], dR[2], g, sm, sa0, fz);
                 const double pq = block_total(dot, sred);       // src/solvers.cpp:602-606
                 pend = 0;
                 if (fabs(pq) < 1e-30) break;
                 alpha = rr / pq;
                 s = 0.0;
-                for (long i = tid; i < NP; i += nt) { const double rn = A.r[i] - alpha * A.q[i]; A.r[i] = rn; s += rn * rn; }
+                for (long i = tid; i < NP; i += nt) { const double rn = wr[i] - alpha * wq[i]; wr[i] = rn; s += rn * rn; }
                 const double rr_new = block_total(s, sred);     // :613-631
                 ++its; pend = 1;
                 if (rr_new < tol_sq) { rr = rr_new; break; }
                 beta = rr_new / rr; rr = rr_new;
             }
-            if (pend) for (long i = tid; i < NP; i += nt) xsol[i] = fma(alpha, A.p[i], xsol[i]);     // the last iteration's x_sol update
+            // the last iteration's x_sol update; the group's solution goes (back) to global memory
+            if (pend) for (long i = tid; i < NP; i += nt) graw[i] = fma(alpha, wp[i], xsol[i]);
+            else if (vx) for (long i = tid; i < NP; i += nt) graw[i] = xsol[i];
             if (tid == 0) A.hist_cg[it * ng + g] = its;
             cg_total += its;
             __syncthreads();
@@ -1432,6 +1523,39 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
         if (dk < A.tol_keff && dphi < A.tol_flux) break;            // :1799-1802
     }
     if (tid == 0) { A.out->keff = keff; A.out->n_outer = n_outer; A.out->status = status; A.out->cg_total = cg_total; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Explicit-S branch of the Schur solver (src/solvers.cpp:114-124, 259-509: direct solver types, a never-pushed solver type,
+// n_phi < 200): S is formed column by column with the matrix-free apply (S e_j), inverted once per BuildMatrices, and a
+// group solve is one dense matrix-vector product.  Column-major n x n.
+__global__ void k_unit_vector(double *__restrict__ v, long n, long j)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) v[i] = i == j ? 1.0 : 0.0;
+}
+// one step of the in-place-style Gauss-Jordan inversion (S is SPD: no pivoting), written out of place so that every entry reads
+// the step's pivot row and column as they were: Mo = step_k(M)
+__global__ void k_gj_step(const double *__restrict__ M, double *__restrict__ Mo, int n, int k)
+{
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= (long)n * n) return;
+    const int i = (int)(idx % n), j = (int)(idx / n);
+    const double p = M[(long)k * n + k], rkj = M[(long)j * n + k], fik = M[(long)k * n + i];
+    double out;
+    if (i == k && j == k) out = 1.0 / p;
+    else if (i == k) out = rkj / p;
+    else if (j == k) out = -fik / p;
+    else out = M[idx] - fik * (rkj / p);
+    Mo[idx] = out;
+}
+// y = Sinv x: one thread per row, consecutive threads read consecutive rows of a column (coalesced)
+__global__ void k_dense_matvec(const double *__restrict__ Sinv, const double *__restrict__ x, double *__restrict__ y, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += Sinv[(long)j * n + i] * x[j];
+    y[i] = s;
 }
 
 // adjoint helpers: sum over groups, weighted dot product, scaling

@@ -67,6 +67,7 @@ struct nfo {
     double **Ms;                            /* ng*ng  : nPhi diagonal of M_scatter[g_to*ng+g_from] or NULL if empty */
     double **Sinv;                          /* diag cache per group */
     int diag_valid;
+    double **Sfac; int **Spiv;              /* explicit Schur complement of a group, LU-factored (direct branch), or NULL */
     /* work */
     double *wt, *wu;                        /* nJ */
     /* stats */
@@ -397,7 +398,9 @@ nfo_t *nfo_create(int rt_order, int p_order, int ng, int nxb, const double *xb, 
 static void free_built(nfo_t *h)
 {
     if (!h->built) return;
-    for (int g = 0; g < h->ng; ++g) { free(h->band[g]); free(h->Aband[g]); free(h->Cd[g]); free(h->Mf[g]); free(h->Mchi[g]); if (h->Sinv && h->Sinv[g]) free(h->Sinv[g]); }
+    for (int g = 0; g < h->ng; ++g) { free(h->band[g]); free(h->Aband[g]); free(h->Cd[g]); free(h->Mf[g]); free(h->Mchi[g]); if (h->Sinv && h->Sinv[g]) free(h->Sinv[g]);
+                                      if (h->Sfac) { free(h->Sfac[g]); free(h->Spiv[g]); } }
+    free(h->Sfac); free(h->Spiv); h->Sfac = NULL; h->Spiv = NULL;
     for (int i = 0; i < h->ng * h->ng; ++i) free(h->Ms[i]);
     free(h->band); free(h->Aband); free(h->Cd); free(h->Mf); free(h->Mchi); free(h->Ms); free(h->Sinv);
     free(h->eJ); free(h->wt); free(h->wu);
@@ -539,6 +542,7 @@ int nfo_build(nfo_t *h)
     h->band = (double **)calloc(ng, sizeof(double *)); h->Aband = (double **)calloc(ng, sizeof(double *));
     h->Cd = (double **)calloc(ng, sizeof(double *)); h->Mf = (double **)calloc(ng, sizeof(double *)); h->Mchi = (double **)calloc(ng, sizeof(double *));
     h->Ms = (double **)calloc((size_t)ng * ng, sizeof(double *)); h->Sinv = (double **)calloc(ng, sizeof(double *));
+    h->Sfac = (double **)calloc(ng, sizeof(double *)); h->Spiv = (int **)calloc(ng, sizeof(int *));
     h->eJ = (int *)malloc(sizeof(int) * ne * nJl);
     h->wt = (double *)malloc(sizeof(double) * nJ); h->wu = (double *)malloc(sizeof(double) * nJ);
     h->built = 1; h->diag_valid = 0; h->cmfd_init = 0;             /* NeutFEM.cpp:454-456 */
@@ -690,6 +694,63 @@ static int cg_solve(nfo_t *h, int g, const double *rhs, double *phi, double tol,
     return its;
 }
 
+/* Explicit branch of the Schur solver (src/solvers.cpp:114-124: direct solver types, a solver type that was never pushed --
+ * SchurSolver's own default is DIRECT_LU, :68 -- or n_phi < 200).  FormSchurComplement (:259-310): S = C + B (A^-1 B^T) column by
+ * column, one A solve per column of B^T, entries of A^-1 B^T with |v| <= 1e-14 dropped (:291).  PrepareSolver / SolveSchurExplicit
+ * (:330-509): Eigen's SparseLU / SimplicialLDLT / SimplicialLLT of S are exact solves; a dense LU with partial pivoting stands for all
+ * three.  For the iterative types at n_phi < 200 the reference runs Eigen's CG / BiCGSTAB on the explicit S to tol_flux (and asserts on
+ * the BiCGSTAB ones); the exact solve stands for those too -- it differs from such an iterate by at most the tolerance.
+ * The factorisation is cached per group until the next BuildMatrices (the reference redoes it in every SetMatrices, :149-179).
+ * Dense storage: meshes beyond NFO_DIRECT_MAX unknowns per group keep the CG-to-1e-14 stand-in below. */
+#define NFO_DIRECT_MAX 6000
+static int schur_explicit_factor(nfo_t *h, int g)
+{
+    if (h->Sfac[g]) return 0;
+    const long n = h->nPhi, nJ = h->nJ;
+    double *S = (double *)calloc((size_t)n * n, sizeof(double)), *e = (double *)calloc(n, sizeof(double));
+    double *col = (double *)malloc(sizeof(double) * nJ), *y = (double *)malloc(sizeof(double) * n);
+    int *piv = (int *)malloc(sizeof(int) * n);
+    for (long j = 0; j < n; ++j) {
+        e[j] = 1.0;
+        apply_BT(h, e, col);                                   /* column j of B^T (chain order) */
+        band_solve(h->band[g], nJ, h->bw, col);                /* A x = B^T[:, j] */
+        for (long i = 0; i < nJ; ++i) if (!(fabs(col[i]) > 1e-14)) col[i] = 0.0;
+        memset(y, 0, sizeof(double) * n);
+        apply_B_add(h, col, y);
+        y[j] += h->Cd[g][j];
+        for (long i = 0; i < n; ++i) S[i * n + j] = y[i];
+        e[j] = 0.0;
+    }
+    int rc = 0;
+    for (long k = 0; k < n && !rc; ++k) {                      /* LU, partial pivoting, row-major in place */
+        long p = k; double best = fabs(S[k * n + k]);
+        for (long i = k + 1; i < n; ++i) if (fabs(S[i * n + k]) > best) { best = fabs(S[i * n + k]); p = i; }
+        piv[k] = (int)p;
+        if (best == 0.0) { rc = -1; break; }
+        if (p != k) for (long c = 0; c < n; ++c) { double t = S[k * n + c]; S[k * n + c] = S[p * n + c]; S[p * n + c] = t; }
+        const double inv = 1.0 / S[k * n + k];
+        for (long i = k + 1; i < n; ++i) {
+            const double l = S[i * n + k] * inv;
+            if (l == 0.0) continue;
+            S[i * n + k] = l;
+            double *ri = S + i * n; const double *rk = S + k * n;
+            for (long c = k + 1; c < n; ++c) ri[c] -= l * rk[c];
+        }
+    }
+    free(e); free(col); free(y);
+    if (rc) { free(S); free(piv); fprintf(stderr, "nf_oracle: explicit Schur complement is singular (group %d)\n", g); return rc; }
+    h->Sfac[g] = S; h->Spiv[g] = piv;
+    return 0;
+}
+static void schur_explicit_solve(const nfo_t *h, int g, const double *rhs, double *phi)
+{
+    const long n = h->nPhi; const double *S = h->Sfac[g]; const int *piv = h->Spiv[g];
+    for (long i = 0; i < n; ++i) phi[i] = rhs[i];
+    for (long k = 0; k < n; ++k) { long p = piv[k]; if (p != k) { double t = phi[k]; phi[k] = phi[p]; phi[p] = t; } }   /* P b (whole rows were swapped) */
+    for (long k = 0; k < n; ++k) { const double v = phi[k]; if (v != 0.0) for (long i = k + 1; i < n; ++i) phi[i] -= S[i * n + k] * v; }
+    for (long k = n - 1; k >= 0; --k) { double v = phi[k]; const double *rk = S + k * n; for (long c = k + 1; c < n; ++c) v -= rk[c] * phi[c]; phi[k] = v / rk[k]; }
+}
+
 /* SchurSolver::Solve, src/solvers.cpp:203-240 (+ SetMatrices :149-179 when refactor_each) */
 int nfo_solve_group(nfo_t *h, int g, const double *rhs, double *phi, double *J)
 {
@@ -698,7 +759,12 @@ int nfo_solve_group(nfo_t *h, int g, const double *rhs, double *phi, double *J)
         band_factor(h->band[g], h->nJ, h->bw);
     }
     int direct = !h->solver_type_pushed || h->solver_type <= 2 || h->nPhi < 200;   /* solvers.cpp:114-124 */
-    int its = direct ? cg_solve(h, g, rhs, phi, 1e-14, (int)(20 * h->nPhi + 50))   /* CG terminates in <= n steps in exact arithmetic */
+    int its;
+    if (direct && h->nPhi <= NFO_DIRECT_MAX && schur_explicit_factor(h, g) == 0) {
+        schur_explicit_solve(h, g, rhs, phi); its = 1;            /* last_iterations_ = 1, solvers.cpp:447 */
+        h->last_cg_its = 1; h->last_cg_res = 0.0;
+    } else
+        its = direct ? cg_solve(h, g, rhs, phi, 1e-14, (int)(20 * h->nPhi + 50))   /* beyond NFO_DIRECT_MAX: CG stands in (<= n steps in exact arithmetic) */
                      : cg_solve(h, g, rhs, phi, h->schur_tol, h->schur_maxit);
     if (J) {                                                   /* J = -A^-1 B^T phi, solvers.cpp:227-228 */
         apply_BT(h, phi, h->wt);

@@ -170,6 +170,7 @@ class RefScipy:
         B.data[np.abs(B.data) <= 1e-14] = 0; B.eliminate_zeros()
         self.B = B; self.BT = B.T.tocsr()
         self.A, self.lu, self.C = [], [], cdiag
+        self._Sfac = {}
         for g in range(ng):
             v = np.concatenate(avals[g]); keep = np.abs(v) > 1e-13 * np.abs(v).max()
             A = sp.coo_matrix((v[keep], (arows[keep], acols[keep])), shape=(self.nJ, self.nJ)).tolil()
@@ -209,6 +210,16 @@ class RefScipy:
             if rrn < tol_sq: break
             p = r + (rrn / rr) * p; rr = rrn
         return x, its
+
+    def direct_solve(self, g, b):                                # solvers.cpp:259-310 (FormSchurComplement) + :441-452 (S_lu_.solve)
+        if g not in self._Sfac:
+            X = self.lu[g].solve(self.BT.toarray())              # A x_j = B^T[:, j] for every column j
+            X[np.abs(X) <= 1e-14] = 0.0                          # :291
+            S = np.diag(self.C[g]) + self.B @ X
+            import scipy.linalg as sla
+            self._Sfac[g] = sla.lu_factor(S)
+        import scipy.linalg as sla
+        return sla.lu_solve(self._Sfac[g], b)
 
     def set_tol(self, tk, tf, tl, mo, mi):
         self.tol = (tk, tf, tl, mo, mi); self.cg_tol = tf; self.cg_max = mi
@@ -302,6 +313,7 @@ class RefScipy:
                 for gp in range(ng):
                     if gp != g and (g, gp) in self.Ms: rhs = rhs + self.Ms[(g, gp)] * self.phi[gp * nP:(gp + 1) * nP]
                 if use_diag: x, its = Sinv[g] * rhs, 0
+                elif getattr(self, "direct", False): x, its = self.direct_solve(g, rhs), 1
                 else: x, its = self.cg(g, rhs)
                 self.phi[g * nP:(g + 1) * nP] = x; cgs.append(its)
             if use_cmfd and it >= 2:                             # :1750-1761 (J = -A^-1 B^T phi, solvers.cpp:227-228)

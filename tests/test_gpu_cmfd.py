@@ -71,7 +71,7 @@ def test_diagonal_solver_with_cmfd_to_convergence(shape, ng, omega):
 
 
 @pytest.mark.parametrize("shape,rt,p,tol", [((9, 1, 1), 0, 0, 1e-9), ((8, 7, 1), 0, 0, 2e-6), ((8, 7, 1), 1, 1, 2e-6), ((6, 5, 4), 1, 1, 1e-7),
-                                            ((8, 7, 1), 2, 2, 2e-5)])
+                                            ((8, 7, 1), 2, 2, 5e-5)])
 def test_full_solver_first_cmfd_step(shape, rt, p, tol):
     """full Schur solver + CMFD: the first correction (outer 2) on small meshes; Sol_J_ mode 0 of every RT order feeds D-hat.
     tol reflects the conditioning of the reference's (indefinite) CMFD matrix, see the module docstring."""

@@ -95,6 +95,38 @@ def test_oracle_vs_scipy_operator_and_solve(shape, rt, p):
     assert rel_l2(o.phi_dofs().ravel(), r.phi) < 1e-8
 
 
+@pytest.mark.parametrize("shape,rt,p,solver", [((9, 1, 1), 0, 0, 6), ((8, 7, 1), 0, 0, 6), ((12, 11, 1), 0, 0, None), ((6, 5, 4), 0, 0, 0), ((8, 7, 1), 1, 1, 1),
+                                               ((5, 4, 3), 1, 0, 2), ((6, 5, 1), 2, 2, None), ((30, 21, 1), 0, 0, 0)])
+def test_oracle_explicit_schur_branch_vs_scipy(shape, rt, p, solver):
+    """explicit-S branch (src/solvers.cpp:114-124, 259-509): n_phi < 200 with any solver type, DIRECT_LU / LDLT / LLT (0 / 1 / 2) at any
+    size, and a solver type that was never pushed (None: SchurSolver's own default is DIRECT_LU, quirk 11).  The oracle forms S
+    column by column with its banded solver and factors it densely; the scipy twin does the same with SuperLU + LAPACK."""
+    inp = synthetic_inputs(*shape, ng=2, seed=sum(shape) + 3 * rt, dirichlet=(1, 2, 3, 5))
+    from oracle.oracle import OracleNeutFEM
+    o = OracleNeutFEM(rt, p, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"])
+    if solver is not None:
+        o.set_linear_solver(solver)
+    for a, t in zip(inp["bc_attr"], inp["bc_type"]):
+        o.set_bc(int(a), int(t), 0.0)
+    o.get_D()[...] = inp["D"]; o.get_SigR()[...] = inp["SigR"]; o.get_NSF()[...] = inp["NSF"]; o.get_Chi()[...] = inp["Chi"]; o.get_SigS()[...] = inp["SigS"]
+    o.BuildMatrices()
+    _, r = _pair(inp, rt, p); r.direct = True
+    assert solver in (None, 0, 1, 2) or o.n_phi < 200
+    rhs = np.random.default_rng(1).standard_normal(o.n_phi)
+    for g in range(2):
+        phi, J, its = o.solve_group(g, rhs)
+        assert its == 1                                              # last_iterations_ = 1 (:447)
+        assert rel_l2(phi, r.direct_solve(g, rhs)) < 1e-11
+        assert rel_l2(o.schur_apply(g, phi), rhs) < 1e-11            # it IS the solution of S phi = rhs
+    tol = (1e-10, 1e-10, 1e-10, 500, 2000)
+    o.set_tol(*tol); r.set_tol(*tol)
+    ko = o.SolveKeff(); kr = r.solve_keff()
+    assert o.info("last_outer") == len(r.hist)
+    assert abs(ko - kr) / kr < 1e-11
+    assert rel_l2(o.phi_dofs().ravel(), r.phi) < 1e-9
+    assert (o.history()["cg"] == 1).all()
+
+
 @pytest.mark.parametrize("shape,rt,p,ng,tol", [((9, 1, 1), 0, 0, 2, 1e-10), ((4, 3, 3), 1, 1, 1, 1e-6), ((8, 7, 1), 0, 0, 2, 1e-5)])
 def test_oracle_cmfd_vs_scipy(shape, rt, p, ng, tol):
     """CMFD (src/NeutFEM.cpp:662-1017): the C oracle (matrix-free 7-point operator) against an explicit scipy matrix with
