@@ -320,6 +320,7 @@ class HipTeam:
             self.slabs.append(HipSolver(rt_order, p_order, ng, x_breaks, y_breaks, zb[k0:k1 + 1], device, lo, hi))
         self.L = self.slabs[0].L
         self.ng = ng
+        self.rt = min(int(rt_order), 2)
         if len(self.slabs) > 1:
             arr = (C.c_void_p * len(self.slabs))(*[s.h for s in self.slabs])
             self.slabs[0]._chk(self.L.nf_link_slabs(arr, len(self.slabs)))
@@ -383,17 +384,23 @@ class HipTeam:
     def synchronize(self): self.head._chk(self.L.nf_synchronize(self.head.h))
 
     def get_J_local(self):
-        """Sol_J_ of the local slabs assembled over their planes: (ng, n_J of the stacked local slabs) in the reference's
-        face numbering (x faces, y faces, z faces).  Collective on a multi-rank run (the z currents cross slabs)."""
-        nx, ny, ng = self.head.nx, self.head.ny, self.ng
-        xs, ys, zs = [], [], []
+        """Sol_J_ of the local slabs assembled over their planes: (ng, n_J of the stacked local slabs) in the reference's DOF
+        numbering (x, y, z face DOFs, then x, y, z bubbles; src/FEM.cpp:264-334).  Collective on a multi-rank run (the z currents
+        cross slabs)."""
+        nx, ny, ng, k = self.head.nx, self.head.ny, self.ng, self.rt
+        nf, ni = (k + 1) ** 2, k * (k + 1) ** 2                   # slabs are 3D: face / interior DOFs per face / cell and direction
+        xs, ys, zs, bub = [], [], [], [[], [], []]
         for i, s in enumerate(self.slabs):
             J = s.get_J()
-            nxf, nyf, nzf = (nx + 1) * ny * s.nz, nx * (ny + 1) * s.nz, nx * ny * (s.nz + 1)
+            nxf, nyf, nzf = (nx + 1) * ny * s.nz * nf, nx * (ny + 1) * s.nz * nf, nx * ny * (s.nz + 1) * nf
             xs.append(J[:, :nxf]); ys.append(J[:, nxf:nxf + nyf])
-            z = J[:, nxf + nyf:nxf + nyf + nzf].reshape(ng, s.nz + 1, ny * nx)
+            z = J[:, nxf + nyf:nxf + nyf + nzf].reshape(ng, s.nz + 1, ny * nx * nf)
             zs.append(z if i == len(self.slabs) - 1 else z[:, :-1])      # the shared interface plane is reported by both neighbours
-        return np.concatenate([np.concatenate(xs, axis=1), np.concatenate(ys, axis=1), np.concatenate(zs, axis=1).reshape(ng, -1)], axis=1)
+            nb = s.ne * ni
+            for d in range(3):
+                bub[d].append(J[:, nxf + nyf + nzf + d * nb:nxf + nyf + nzf + (d + 1) * nb])
+        return np.concatenate([np.concatenate(xs, axis=1), np.concatenate(ys, axis=1), np.concatenate(zs, axis=1).reshape(ng, -1)] +
+                              [np.concatenate(b, axis=1) for b in bub], axis=1)
 
     def get_phi_local(self):
         """(ng, local planes, ny, nx)"""

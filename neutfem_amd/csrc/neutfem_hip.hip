@@ -173,7 +173,8 @@ struct nf_solver {
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
     CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
     CgLean lean_z1 = { nullptr, nullptr, 0, 0, 0 };     // slab teams: the endpoint pass of the z lines consumes the all-reduced |r|^2
-    double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nx*ny*(nz+1) (nf_get_J)
+    double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nJz face DOFs (nf_get_J)
+    double *d_Jzb = nullptr;                            // slabs, RT1+: z bubbles of the local cells, ng * N * ni
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
     bool cmfd_init = false; double cmfd_relax = 1.0;
     double *d_Dt[3] = {nullptr, nullptr, nullptr}, *d_Dh[3] = {nullptr, nullptr, nullptr}; long nfc[3] = {0, 0, 0};
@@ -426,7 +427,7 @@ int nf_destroy(nf_handle S)
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
-    dfree(S->d_Jz); dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
+    dfree(S->d_Jz); dfree(S->d_Jzb); dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
     dfree(S->d_phi); dfree(S->d_raw); dfree(S->d_p0); dfree(S->d_p1);
     dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q); dfree(S->d_p2); dfree(S->d_qy); dfree(S->d_qz);
     if (T) {
@@ -875,7 +876,16 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
         const long nl = S->nlines[2];
         sa.if_lo = S->if_lo; sa.if_hi = S->if_hi; sa.mode = zmode;
         sa.alo = S->d_alo + g * nl; sa.ahi = S->d_ahi + g * nl; sa.ulo = S->d_ulo; sa.uhi = S->d_uhi; sa.clo = S->d_clo; sa.chi = S->d_chi;
-        sa.jz = zmode == 3 ? S->d_Jz + (size_t)g * nl * (S->nz + 1) : nullptr;
+        if (zmode == 3) {                                           // current reconstruction: face DOFs and bubbles of every transverse mode
+            int nfa = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nfa *= S->k + 1; ni *= S->k + 1; }
+            sa.nfa = nfa; sa.ni = ni;
+            sa.jz = S->d_Jz + (size_t)g * S->nJz; sa.jzb = S->d_Jzb ? S->d_Jzb + (size_t)g * S->N * ni : nullptr;
+            for (int m = 0; m < mt.n && m < 9; ++m) {                // RT transverse index of P mode m: a = sum a_t (k+1)^t (src/FEM.cpp:364-374)
+                int amode = 0, q = m, mul = 1;
+                for (int t = 0; t < S->dim; ++t) { if (t == d) continue; amode += (q % S->n1) * mul; q /= S->n1; mul *= S->k + 1; }
+                sa.amode[m] = amode;
+            }
+        }
         if (zmode == 2 && T->sep_sweeps == 0 && T->opt_sepfold) {     // separators formed inside the pass (no k_separators launch)
             sa.fold = 1; sa.rlo = S->d_rlo; sa.rhi = S->d_rhi; sa.sinv_lo = S->d_sinv_lo + g * nl; sa.sinv_hi = S->d_sinv_hi + g * nl;
         }
@@ -1311,7 +1321,15 @@ static int team_reconstruct_Jz(nf_team *T)
     if (all) return NF_OK;
     NFCHK(team_prepare(T));
     const int ns = (int)T->slabs.size(), ng = T->slabs[0]->ng;
-    for (auto *S : T->slabs) if (!S->d_Jz) NFCHK(dalloc(&S->d_Jz, (size_t)S->nJz * ng));
+    for (auto *S : T->slabs) {
+        if (!S->d_Jz) NFCHK(dalloc(&S->d_Jz, (size_t)S->nJz * ng));
+        HIPCHK(hipMemsetAsync(S->d_Jz, 0, (size_t)S->nJz * ng * sizeof(double), T->stream));         // RT modes that see no phi moment stay 0
+        if (S->k > 0) {
+            int ni = S->k; for (int t = 1; t < S->dim; ++t) ni *= S->k + 1;
+            if (!S->d_Jzb) NFCHK(dalloc(&S->d_Jzb, (size_t)S->N * ni * ng));
+            HIPCHK(hipMemsetAsync(S->d_Jzb, 0, (size_t)S->N * ni * ng * sizeof(double), T->stream));
+        }
+    }
     std::vector<const double *> xs(ns); std::vector<double *> ys(ns);
     for (int g = 0; g < ng; ++g) {
         for (int i = 0; i < ns; ++i) { xs[i] = T->slabs[i]->d_raw + (size_t)g * T->slabs[i]->nphi; ys[i] = T->slabs[i]->d_q; }
@@ -1322,6 +1340,48 @@ static int team_reconstruct_Jz(nf_team *T)
             NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, nullptr, nullptr, 3));
         }
         HIPCHK(hipStreamSynchronize(T->stream));                  // the exchange buffers are reused by the next group
+    }
+    HIPCHK(hipGetLastError());
+    for (auto *S : T->slabs) S->jz_valid = true;
+    return NF_OK;
+}
+
+// z currents of every local slab after a diagonal-Schur solve (J_f = +(B^T phi)_f / A_ff, src/NeutFEM.cpp:620-633): per group
+// one plane of edge-cell a2 and one of edge-cell phi per interface go to the neighbour; collective like team_reconstruct_Jz.
+static int team_reconstruct_Jz_diag(nf_team *T)
+{
+    bool all = true; for (auto *S : T->slabs) all &= S->jz_valid;
+    if (all) return NF_OK;
+    NFCHK(team_prepare(T));
+    const int ng = T->slabs[0]->ng;
+    hipStream_t st = T->stream;
+    for (auto *S : T->slabs) if (!S->d_Jz) NFCHK(dalloc(&S->d_Jz, (size_t)S->nJz * ng));
+    for (int g = 0; g < ng; ++g) {
+        // (1) a2 of the edge cells -> d_rlo / d_rhi ; kept in d_ctlo / d_cthi while the planes are reused for phi
+        for (auto *S : T->slabs) {
+            const long nl = S->nlines[2];
+            hipLaunchKernelGGL(k_edge_a2, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, make_geom(S), S->d_D + g * S->N, S->d_clo, S->d_chi, nl);
+        }
+        NFCHK(exchange_planes(T, 0, 0, st));
+        for (auto *S : T->slabs) {
+            const size_t b = (size_t)S->nlines[2] * sizeof(double);
+            HIPCHK(hipMemcpyAsync(S->d_ctlo, S->d_rlo, b, hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(S->d_cthi, S->d_rhi, b, hipMemcpyDeviceToDevice, st));
+        }
+        // (2) phi of the edge cells (first and last plane of the raw group flux)
+        for (auto *S : T->slabs) {
+            const size_t b = (size_t)S->nlines[2] * sizeof(double);
+            const double *raw = S->d_raw + (size_t)g * S->nphi;
+            HIPCHK(hipMemcpyAsync(S->d_clo, raw, b, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(S->d_chi, raw + (size_t)(S->nz - 1) * S->nlines[2], b, hipMemcpyDeviceToDevice, st));
+        }
+        NFCHK(exchange_planes(T, 0, 0, st));
+        for (auto *S : T->slabs) {
+            const long nl = S->nlines[2];
+            hipLaunchKernelGGL(k_diag_Jz_slab, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, make_geom(S), S->d_D + g * S->N, S->d_raw + (size_t)g * S->nphi,
+                               S->d_Jz + (size_t)g * S->nJz, nl, S->if_lo, S->if_hi, (const double *)S->d_rlo, (const double *)S->d_ctlo,
+                               (const double *)S->d_rhi, (const double *)S->d_cthi);
+        }
+        HIPCHK(hipStreamSynchronize(st));                         // the exchange buffers are reused by the next group
     }
     HIPCHK(hipGetLastError());
     for (auto *S : T->slabs) S->jz_valid = true;
@@ -1339,9 +1399,8 @@ int nf_get_J(nf_handle S, double *J_host)
     if (slab) {
         // z currents cross slabs: one partition-method solve per group on the raw group fluxes, for the whole team (collective:
         // every rank calls nf_get_J on its slabs in the same order; the first call after a solve does the work for all local slabs)
-        if (S->raw_is_diag) return fail(NF_ERR_UNSUPPORTED, "nf_get_J on a slab after a diagonal-Schur solve is not available");
-        if (S->k != 0) return fail(NF_ERR_UNSUPPORTED, "nf_get_J on a slab is implemented for RT0 only");
-        NFCHK(team_reconstruct_Jz(S->team));
+        if (S->raw_is_diag) NFCHK(team_reconstruct_Jz_diag(S->team));       // RT0-P0 by construction (the diagonal path exists for that order only)
+        else NFCHK(team_reconstruct_Jz(S->team));
     }
     DevTmp<double> dJ_; NFCHK(dalloc(&dJ_.p, (size_t)nJ)); double *dJ = dJ_.p;
     Geom G = make_geom(S);
@@ -1360,7 +1419,11 @@ int nf_get_J(nf_handle S, double *J_host)
                                    S->d_D + g * N, S->d_L[d] + g * N, S->d_DR[d] + g * N, S->d_D0[d] + g * S->nlines[d],
                                    dJ + foff[d], dJ + nJface + (long)d * N * ni, S->nlines[d], S->raw_is_diag ? 1 : 0);
             }
-        if (slab) HIPCHK(hipMemcpyAsync(dJ + foff[2], S->d_Jz + (size_t)g * S->nJz, S->nJz * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (slab) {
+            HIPCHK(hipMemcpyAsync(dJ + foff[2], S->d_Jz + (size_t)g * S->nJz, S->nJz * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (ni > 0 && !S->raw_is_diag && S->d_Jzb)
+                HIPCHK(hipMemcpyAsync(dJ + nJface + 2L * N * ni, S->d_Jzb + (size_t)g * N * ni, (size_t)N * ni * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
         HIPCHK(hipMemcpyAsync(J_host + (size_t)g * nJ, dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }

@@ -657,7 +657,9 @@ struct SlabArgs {
     int wsmin;                                // segments from which the wavefront scan of the summaries replaces the serial loops (0: default 64)
     const double *alo, *ahi, *ulo, *uhi;      // per line
     double *clo, *chi;                        // per line (mode 1 outputs)
-    double *jz;                               // mode 3: J = -u on the slab's own z faces [(face) * nx * ny + line] (Sol_J_, src/solvers.cpp:228)
+    double *jz;                               // mode 3: J = -u on the slab's own z faces [((face) * nx * ny + line) * nfa + amode] (Sol_J_, src/solvers.cpp:228)
+    double *jzb;                              // mode 3, RT1+: the z bubbles of the slab's cells [cell * ni + l + k * amode] (src/FEM.cpp:377-397)
+    int nfa, ni, amode[9];                    // RT face / interior DOFs per face / cell and direction; RT transverse index of every P mode
 };
 // One tile (TX columns x one line each, NSEG segments) of a y / z pass.  tid = thread index within the tile; threads with
 // act == false only keep the barriers company.  acc: accumulate into y (the x pass ran before) or store the increment alone
@@ -869,16 +871,42 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             }
         }
     }
-    if (SLAB && sa.mode == 3) {                                 // emit J_z = -u on every face of the local line
+    if (SLAB && sa.mode == 3) {                                 // emit J_z = -u on every face of the local line (+ the z bubbles for RT1+)
         if (valid) {
             const long nxy = sl;                                 // z lines: stride between planes = nx * ny
-            const int fs = sa.if_lo ? 1 : 0;
+            const int fs = sa.if_lo ? 1 : 0, am = sa.amode[bz], nfa = sa.nfa, kb = G.k;
+            auto face = [&](long fpl) -> double & { return sa.jz[(fpl * nxy + lineid) * nfa + am]; };
+            // bubbles of a cell between face values (lo, hi): v_l = G_l x_{l+1} iM_l / c_e - (eL_l lo + eR_l hi); inactive ones (l >= NB) have no source
+            auto bubbles = [&](long cell, double lo, double hi, double xb1, double xb2, double ice) {
+                for (int l = 0; l < kb; ++l) {
+                    const double xb = l == 0 ? xb1 : xb2;
+                    const double tb = l < NB ? ma.Gc[l] * xb * ma.iM[l] * ice : 0.0;
+                    sa.jzb[cell * sa.ni + l + kb * am] = -(tb - (ma.eL[l] * lo + ma.eR[l] * hi));
+                }
+            };
 #pragma unroll
-            for (int i = 0; i < SEG; ++i) if (c0 + i < n) sa.jz[(long)(fs + c0 + i + 1) * nxy + lineid] = -w[i];
+            for (int i = 0; i < SEG; ++i) if (c0 + i < n) {
+                face(fs + c0 + i + 1) = -w[i];
+                if (kb > 0) bubbles((long)(fs + c0 + i) * nxy + lineid, i == 0 ? ulo : w[i > 0 ? i - 1 : 0], w[i], NB > 0 ? x1[NB > 0 ? i : 0] : 0.0, NB > 1 ? x2[NB > 1 ? i : 0] : 0.0,
+                                    NB > 0 ? icv[NB > 0 ? i : 0] : 0.0);
+            }
             if (seg == 0) {
-                sa.jz[(long)fs * nxy + lineid] = -ulo;           // lower face of the first chain cell
-                if (sa.if_lo) sa.jz[lineid] = -sa.ulo[lm];       // the separators themselves
-                if (sa.if_hi) sa.jz[(long)(fs + n + 1) * nxy + lineid] = -sa.uhi[lm];
+                face(fs) = -ulo;                                 // lower face of the first chain cell
+                if (sa.if_lo) {
+                    const double us = sa.ulo[lm];
+                    face(0) = -us;                               // the separator below
+                    if (kb > 0) bubbles(lineid, us, ulo, NB > 0 ? ma.x[NB > 0 ? 1 : 0][edge_lo] : 0.0, NB > 1 ? ma.x[NB > 1 ? 2 : 0][edge_lo] : 0.0,
+                                        NB > 0 ? ma.D[edge_lo] / geom_factor(G, DIR, ix, (int)by, 0) : 0.0);
+                }
+            }
+            if (sa.if_hi && c0 <= n - 1 && n - 1 < c0 + SEG) {     // the thread that owns the last chain cell: separator above + upper edge cell
+                double ulast = 0.0;
+#pragma unroll
+                for (int i = 0; i < SEG; ++i) if (c0 + i == n - 1) ulast = w[i];
+                const double us = sa.uhi[lm];
+                face(fs + n + 1) = -us;
+                if (kb > 0) bubbles((long)(fs + n) * nxy + lineid, ulast, us, NB > 0 ? ma.x[NB > 0 ? 1 : 0][edge_hi] : 0.0, NB > 1 ? ma.x[NB > 1 ? 2 : 0][edge_hi] : 0.0,
+                                    NB > 0 ? ma.D[edge_hi] / geom_factor(G, DIR, ix, (int)by, fs + n) : 0.0);
             }
         }
         return 0.0;
@@ -1025,7 +1053,7 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
         const int r = b < (unsigned)(A.nbx + A.nby) ? 0 : 1;
         const unsigned t = b - A.nbx - (r ? A.nby : 0);
         const unsigned bx = t % A.gx[r], by = (t / A.gx[r]) % A.gy[r], bz = t / (A.gx[r] * A.gy[r]);
-        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = sa.wsmin = sa.fold = 0; sa.alo = sa.ahi = sa.ulo = sa.uhi = sa.rlo = sa.rhi = sa.sinv_lo = sa.sinv_hi = nullptr; sa.clo = sa.chi = sa.jz = nullptr;
+        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = sa.wsmin = sa.fold = 0; sa.alo = sa.ahi = sa.ulo = sa.uhi = sa.rlo = sa.rhi = sa.sinv_lo = sa.sinv_hi = nullptr; sa.clo = sa.chi = sa.jz = sa.jzb = nullptr; sa.nfa = 1; sa.ni = 0;
         if (r == 0) {
             const ModeArgs ma = select_mode(may0, mty, bz, NB + 1);
             dot = schur_s_tile<SEG, 1, false, NB>(ma, G, Ly, DRy, D0y, A.n[0], A.sl[0], A.ostride[0], nx, A.TX[0], A.NSEG[0], bx, by, bz, A.gy[0],
@@ -1390,7 +1418,7 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
     double *sred = sm + 5 * (int)blockDim.x + 64;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
     const int ng = A.ng; const long N = A.N, NP = A.nphi, NT = NP * ng;
-    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = nullptr;
+    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
     // vectors and factors that fit are kept in LDS behind the scratch area (ResidentArgs::lds_mask); the rest stays in global memory
     double *lds = sm + 5 * (int)blockDim.x + 64 + 16;
     long lo = 0;
@@ -1688,6 +1716,30 @@ __global__ void k_flux_to_J(Geom G, ModeArgs ma, int nb, int amode, int nfa, int
         }
     }
 #undef JF
+}
+
+// Diagonal-path currents of the z faces of a slab (src/NeutFEM.cpp:620-633: J_f = (B^T phi)_f / A_ff): the interface faces take the
+// neighbour's edge-cell value and a2 (one plane each, exchanged by the caller); both slabs of an interface report the same number.
+__global__ void k_diag_Jz_slab(Geom G, const double *__restrict__ D, const double *__restrict__ x, double *__restrict__ jz, long nlines,
+                               int if_lo, int if_hi, const double *__restrict__ nb_x_lo, const double *__restrict__ nb_a2_lo,
+                               const double *__restrict__ nb_x_hi, const double *__restrict__ nb_a2_hi)
+{
+    const long line = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (line >= nlines) return;
+    const int ix = (int)(line % G.nx), iy = (int)(line / G.nx), n = G.nz;
+    const long nxy = (long)G.nx * G.ny;
+    double a2p = if_lo ? nb_a2_lo[line] : 0.0, xp = if_lo ? nb_x_lo[line] : 0.0, Dp = 0.0, a1;
+    for (int f = 0; f <= n; ++f) {
+        double a2 = 0.0, xc = 0.0, Dc = 0.0;
+        if (f < n) { Dc = D[line + (long)f * nxy]; cell_a(G, 2, ix, iy, f, Dc, a2, a1); xc = x[line + (long)f * nxy]; }
+        else if (if_hi) { a2 = nb_a2_hi[line]; xc = nb_x_hi[line]; }
+        double Aff = a2p + a2;
+        if (f == 0 && G.dir_lo[2]) Aff += dirichlet_term(G, 2, ix, iy, 0, Dc);
+        if (f == n && G.dir_hi[2]) Aff += dirichlet_term(G, 2, ix, iy, n - 1, Dp);
+        const double tt = xp - xc;
+        jz[(long)f * nxy + line] = fabs(G.T0 * Aff) < 1e-14 ? 0.0 : tt / Aff;
+        a2p = a2; xp = xc; Dp = Dc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

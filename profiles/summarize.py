@@ -71,7 +71,9 @@ def main():
         kernels[k] = dict(dispatches=max(len(fetch.get(k, [])), len(write.get(k, []))), fetch_kib_raw=fm, write_kib=wm,
                           read_bytes_per_cell_corrected=round(2.0 * fm * 1024 / cells, 3), write_bytes_per_cell=round(wm * 1024 / cells, 3),
                           hbm_bytes_per_cell=round((2.0 * fm + wm) * 1024 / cells, 3))
-    doc = dict(command="profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, each with --kernel-trace only)",
+    commit = os.environ.get("NEUTFEM_COMMIT")                     # the GPU box has no .git: collect.sh is given the commit by the caller
+    doc = dict(tag=tag, commit=commit,
+               command="profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, each with --kernel-trace only)",
                mesh="IAEA-3D resampled 256^3", cells=cells,
                units="counter values are KiB per dispatch (median of the upper half of the dispatches); bytes_per_cell = KiB*1024/cells",
                gfx950_correction="FETCH_SIZE x2 (calibration: k_cg_rupdate reads r,q = 16 B/cell); WRITE_SIZE exact", kernels=kernels)

@@ -148,6 +148,12 @@ def test_team_diagonal_path_matches_oracle(planes):
     for g in range(2):
         sinv = np.concatenate([s.diagonal_cache(g) for s in t.slabs])
         assert np.abs(sinv / o.diag_cache(g) - 1).max() < 1e-14
+    # Sol_J_ after a diagonal solve (J_f = +(B^T phi)_f / A_ff, src/NeutFEM.cpp:620-633): the interface z faces need the neighbour's
+    # edge cells (one phi plane and one a2 plane per interface and group)
+    J = t.get_J_local()
+    assert J.shape == (2, o.n_J) and rel_l2(J.ravel(), o.J_dofs().ravel()) < 1e-9
+    lo = o.info("n_Jx") + o.info("n_Jy")
+    assert np.abs(J[:, lo:] - o.J_dofs()[:, lo:]).max() <= 1e-12 * np.abs(o.J_dofs()[:, lo:]).max()
     t.close()
 
 
@@ -167,6 +173,25 @@ def test_team_currents_match_oracle(planes):
     assert rel_l2(J.ravel(), o.J_dofs().ravel()) < 1e-7
     for lo, hi in ((0, o.info("n_Jx")), (o.info("n_Jx") + o.info("n_Jy"), o.n_J)):      # x faces and z faces separately
         assert rel_l2(J[:, lo:hi].ravel(), o.J_dofs()[:, lo:hi].ravel()) < 1e-7
+    t.close()
+
+
+@pytest.mark.parametrize("rt,p", [(1, 1), (1, 0), (2, 2), (2, 1)])
+@pytest.mark.parametrize("shape,planes", [((5, 4, 20), [(0, 9), (9, 20)]), ((4, 3, 30), [(0, 10), (10, 20), (20, 30)])])
+def test_team_currents_higher_orders(shape, planes, rt, p):
+    """Sol_J_ of RT1 / RT2 on slabs: the partition-method solve in emit mode stores, per transverse mode, the face DOFs of every local
+    z face (separators included) and the z bubbles of every local cell (edge cells included); x / y DOFs are slab-local"""
+    inp = synthetic_inputs(*shape, ng=2, seed=21 + rt, dirichlet=(1, 2, 3, 5, 6))
+    o, t = make_oracle(inp, rt, p), make_team_order(inp, planes, rt, p)
+    tol = (1e-12, 1e-11, 1e-11, 12, 3000)                          # fixed work: 12 outers, tight inner solves
+    o.set_tol(*tol); t.set_tol(*tol)
+    ko = o.SolveKeff(); kt, _ = t.solve_keff()
+    assert abs(kt - ko) / ko < 1e-9
+    J, Jo = t.get_J_local(), o.J_dofs()
+    assert J.shape == Jo.shape
+    nface = o.info("n_Jx") + o.info("n_Jy") + o.info("n_Jz")
+    for lo, hi in ((0, o.info("n_Jx") + o.info("n_Jy")), (o.info("n_Jx") + o.info("n_Jy"), nface), (nface, o.n_J)):   # x/y faces, z faces, bubbles
+        assert rel_l2(J[:, lo:hi].ravel(), Jo[:, lo:hi].ravel()) < 1e-7, (lo, hi)
     t.close()
 
 
