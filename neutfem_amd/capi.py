@@ -365,8 +365,12 @@ class HipTeam:
     def build(self):
         for s in self.slabs: s.build()
 
-    def solve_keff(self, use_coarse=False, factors=(), profile=False, use_diag=False):
-        return self.head.solve_keff(use_coarse, factors, use_diag, profile)
+    def solve_keff(self, use_coarse=False, factors=(), profile=False, use_diag=False, use_cmfd=False):
+        return self.head.solve_keff(use_coarse, factors, use_diag, profile, use_cmfd)
+
+    def set_cmfd_relaxation(self, omega):
+        for s in self.slabs:
+            s.set_cmfd_relaxation(omega)
 
     def reset_flux(self):
         for s in self.slabs: s.reset_flux()

@@ -176,7 +176,7 @@ struct nf_solver {
     double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nJz face DOFs (nf_get_J)
     double *d_Jzb = nullptr;                            // slabs, RT1+: z bubbles of the local cells, ng * N * ni
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
-    bool cmfd_init = false; double cmfd_relax = 1.0;
+    bool cmfd_init = false, cmfd_iface = false; double cmfd_relax = 1.0;
     double *d_Dt[3] = {nullptr, nullptr, nullptr}, *d_Dh[3] = {nullptr, nullptr, nullptr}; long nfc[3] = {0, 0, 0};
     double *d_cm = nullptr, *d_cmJ = nullptr; CmfdScalars *d_cmsc = nullptr;
     int cmfd_last_its = 0;
@@ -556,7 +556,7 @@ int nf_upload_xs(nf_handle S, const double *D, const double *SigR, const double 
     const size_t NN = (size_t)S->N * S->ng, B = NN * sizeof(double);
     // the device copies are overwritten from here on: whatever was built from the old ones is stale until the next nf_build,
     // also when this upload is refused below (a refused upload leaves the handle un-built, never half-valid)
-    S->xs_uploaded = false; S->built = false; S->diag_valid = false; S->cmfd_init = false; S->dense_valid = false;
+    S->xs_uploaded = false; S->built = false; S->diag_valid = false; S->cmfd_init = false; S->cmfd_iface = false; S->dense_valid = false;
     coarse_cache_drop(S->team);
     NFCHK(dalloc(&S->d_D, NN)); NFCHK(dalloc(&S->d_SigR, NN)); NFCHK(dalloc(&S->d_NSF, NN)); NFCHK(dalloc(&S->d_Chi, NN));
     HIPCHK(hipMemcpyAsync(S->d_D, D, B, hipMemcpyHostToDevice, st));
@@ -655,7 +655,7 @@ int nf_build(nf_handle S)
     if (!S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NP * ng)); NFCHK(dalloc(&S->d_p1, (size_t)NP * ng)); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    S->built = true; S->diag_valid = false; S->cmfd_init = false; S->dense_valid = false;   // src/NeutFEM.cpp:454-456
+    S->built = true; S->diag_valid = false; S->cmfd_init = false; S->cmfd_iface = false; S->dense_valid = false;   // src/NeutFEM.cpp:454-456
     S->team->linked_ready = false;
     return NF_OK;
 }
@@ -1602,7 +1602,6 @@ int nf_solve_coarse(nf_handle S, const nf_keff_opts *o, double *k_coarse, double
 static int cmfd_initialize(nf_solver *S)
 {
     if (S->cmfd_init) return NF_OK;
-    if (S->if_lo || S->if_hi) return fail(NF_ERR_UNSUPPORTED, "CMFD is not available on a slab-decomposed mesh");
     hipStream_t st = S->team->stream;
     const int ng = S->ng; const long N = S->N;
     S->nfc[0] = (long)(S->nx + 1) * S->ny * S->nz; S->nfc[1] = (long)S->nx * (S->ny + 1) * S->nz; S->nfc[2] = (long)S->nx * S->ny * (S->nz + 1);
@@ -1622,12 +1621,14 @@ static int cmfd_initialize(nf_solver *S)
     S->cmfd_init = true;
     return NF_OK;
 }
+static int cmfd_initialize_team(nf_team *T);
 int nf_initialize_cmfd(nf_handle S)
 {
     if (!S) return fail(NF_ERR_ARG, "null handle");
     if (!S->built) return fail(NF_ERR_STATE, "nf_initialize_cmfd: call nf_build first");
     HIPCHK(hipSetDevice(S->device));
-    NFCHK(cmfd_initialize(S));
+    for (auto *X : S->team->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_initialize_cmfd: every slab of the team must be built first");
+    NFCHK(cmfd_initialize_team(S->team));                        // collective on a multi-rank team (interface D-tilde)
     HIPCHK(hipStreamSynchronize(S->team->stream));
     return NF_OK;
 }
@@ -1674,7 +1675,7 @@ static int cmfd_step(nf_solver *S, double keff, int use_diag)
         CmfdScalars hs; hs.done = 0; hs.its = 0;
         for (int base = 0; base < 100 && !hs.done; base += 10) {
             for (int i = 0; i < 10; ++i) {
-                hipLaunchKernelGGL(k_cmfd_matvec, dim3(gN), dim3(256), 0, st, G, F, diag, pp, q, N, S->d_cmsc, T->d_partials);
+                hipLaunchKernelGGL(k_cmfd_matvec, dim3(gN), dim3(256), 0, st, G, F, diag, pp, q, N, S->d_cmsc, T->d_partials, (const double *)nullptr, (const double *)nullptr);
                 hipLaunchKernelGGL(k_cmfd_logic, dim3(1), dim3(256), 0, st, 1, T->d_partials, gN, stride, S->d_cmsc);
                 hipLaunchKernelGGL(k_cmfd_update, dim3(gN), dim3(256), 0, st, diag, pp, q, x, r, z, N, S->d_cmsc, T->d_partials, stride);
                 hipLaunchKernelGGL(k_cmfd_logic, dim3(1), dim3(256), 0, st, 2, T->d_partials, gN, stride, S->d_cmsc);
@@ -1685,6 +1686,132 @@ static int cmfd_step(nf_solver *S, double keff, int use_diag)
         }
         S->cmfd_last_its += hs.its;
         hipLaunchKernelGGL(k_cmfd_correct, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, S->d_raw + (size_t)g * NP, N, S->nloc, S->cmfd_relax);
+    }
+    HIPCHK(hipGetLastError());
+    return NF_OK;
+}
+
+// CMFD on a slab team: every slab initialises its own faces; the D-tilde of an interface z face couples the edge cells of two slabs
+// (one plane of D per group and the edge cell height travel to the neighbour, once per BuildMatrices).
+static int cmfd_initialize_team(nf_team *T)
+{
+    bool done = true, any_if = false;
+    for (auto *S : T->slabs) { done &= S->cmfd_init && S->cmfd_iface; any_if |= S->if_lo || S->if_hi; }
+    if (done) return NF_OK;
+    for (auto *S : T->slabs) NFCHK(cmfd_initialize(S));
+    if (any_if) {
+        NFCHK(team_prepare(T));
+        hipStream_t st = T->stream;
+        const int ng = T->slabs[0]->ng;
+        for (int g = 0; g < ng; ++g) {
+            for (auto *S : T->slabs) {                            // edge planes of D
+                const size_t b = (size_t)S->nlines[2] * sizeof(double);
+                HIPCHK(hipMemcpyAsync(S->d_clo, S->d_D + (size_t)g * S->N, b, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(S->d_chi, S->d_D + (size_t)g * S->N + (size_t)(S->nz - 1) * S->nlines[2], b, hipMemcpyDeviceToDevice, st));
+            }
+            NFCHK(exchange_planes(T, 0, 0, st));
+            for (auto *S : T->slabs) {
+                const size_t b = (size_t)S->nlines[2] * sizeof(double);
+                HIPCHK(hipMemcpyAsync(S->d_ctlo, S->d_rlo, b, hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(S->d_cthi, S->d_rhi, b, hipMemcpyDeviceToDevice, st));
+                const int gr = grid_for(S->nlines[2]);
+                hipLaunchKernelGGL(k_fill_const, dim3(gr), dim3(256), 0, st, S->d_clo, S->nlines[2], S->hz.front());   // edge cell heights
+                hipLaunchKernelGGL(k_fill_const, dim3(gr), dim3(256), 0, st, S->d_chi, S->nlines[2], S->hz.back());
+            }
+            NFCHK(exchange_planes(T, 0, 0, st));
+            for (auto *S : T->slabs) {
+                const long nl = S->nlines[2]; const unsigned gr = (unsigned)((nl + 255) / 256);
+                double *Dt = S->d_Dt[2] + (size_t)g * S->nfc[2];
+                if (S->if_lo) hipLaunchKernelGGL(k_cmfd_dtilde_iface, dim3(gr), dim3(256), 0, st, (const double *)(S->d_D + (size_t)g * S->N), (const double *)S->d_ctlo,
+                                                 (const double *)S->d_rlo, S->hz.front(), Dt, nl, 1);
+                if (S->if_hi) hipLaunchKernelGGL(k_cmfd_dtilde_iface, dim3(gr), dim3(256), 0, st, (const double *)(S->d_D + (size_t)g * S->N + (size_t)(S->nz - 1) * nl),
+                                                 (const double *)S->d_cthi, (const double *)S->d_rhi, S->hz.back(), Dt + (size_t)S->nz * nl, nl, 0);
+            }
+            HIPCHK(hipStreamSynchronize(st));                     // the exchange planes are reused by the next group
+        }
+        HIPCHK(hipGetLastError());
+    }
+    for (auto *S : T->slabs) S->cmfd_iface = true;
+    return NF_OK;
+}
+
+// UpdateDhat + ApplyCMFDCorrection on a slab team (:1750-1761): the PCG of cmfd_step with one plane of p per interface and
+// iteration (7-point stencil across the cut) and team-wide dot products (process-local sums + all-reduce over ranks); the CG
+// scalars live in the first local slab's CmfdScalars.  Same arithmetic per cell as the undivided solve.
+static int cmfd_step_team(nf_team *T, double keff, int use_diag)
+{
+    hipStream_t st = T->stream;
+    const int ns = (int)T->slabs.size(), ng = T->slabs[0]->ng;
+    CmfdScalars *sc = T->slabs[0]->d_cmsc;
+    std::vector<int> gN(ns);
+    for (int i = 0; i < ns; ++i) gN[i] = grid_for(T->slabs[i]->N);
+    auto reduce_logic = [&](int op, int nq) -> int {
+        PartSegs ps = segs_for(T, gN);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, nq, T->d_cg, T->d_red, 0.0, 0, 1, T->d_red);
+        if (T->rccl_reduce) NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq, NCCL_DOUBLE, NCCL_SUM, T->comm, st));
+        hipLaunchKernelGGL(k_cmfd_logic_tot, dim3(1), dim3(1), 0, st, op, (const double *)T->d_red, sc);
+        return NF_OK;
+    };
+    for (auto *S : T->slabs) {                                    // D-hat: x faces only, slab-local (x lines do not cross slabs)
+        const long N = S->N, NP = S->nphi;
+        Geom G = make_geom(S);
+        int nfa = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nfa *= S->k + 1; ni *= S->k + 1; }
+        const long nJface = S->nJx + S->nJy + S->nJz;
+        for (int g = 0; g < ng; ++g) {
+            ModeArgs ma = mode_args(S, g, 0, 0, S->d_raw + (size_t)g * NP, S->d_raw + (size_t)g * NP);
+            hipLaunchKernelGGL(k_flux_to_J, dim3((unsigned)((S->nlines[0] + 63) / 64)), dim3(64), 0, st, G, ma, S->nb, 0, nfa, ni,
+                               S->d_D + g * N, S->d_L[0] + g * N, S->d_DR[0] + g * N, S->d_D0[0] + g * S->nlines[0],
+                               S->d_cmJ, S->d_cmJ + nJface, S->nlines[0], use_diag);
+            hipLaunchKernelGGL(k_cmfd_dhat, dim3((unsigned)((S->nfc[0] + 255) / 256)), dim3(256), 0, st, G, S->d_raw + (size_t)g * NP, S->d_cmJ, nfa,
+                               S->d_Dt[0] + g * S->nfc[0], S->d_Dh[0] + g * S->nfc[0], S->nfc[0]);
+        }
+        S->cmfd_last_its = 0;
+    }
+    for (int g = 0; g < ng; ++g) {
+        for (int i = 0; i < ns; ++i) {
+            nf_solver *S = T->slabs[i]; const long N = S->N;
+            CmfdFaces F; for (int d = 0; d < 3; ++d) { F.Dt[d] = S->d_Dt[d] + g * S->nfc[d]; F.Dh[d] = S->d_Dh[d] + g * S->nfc[d]; }
+            double *diag = S->d_cm, *x = diag + N, *r = x + N, *pp = r + N;
+            hipLaunchKernelGGL(k_cmfd_setup, dim3(gN[i]), dim3(256), 0, st, make_geom(S), F, S->d_Cd + (size_t)g * S->nphi, S->d_Chi + g * N, S->d_tf, 1.0 / keff,
+                               diag, x, r, pp, N, T->d_partials + i * T->slab_cap, T->partial_stride);
+        }
+        NFCHK(reduce_logic(0, 2));
+        CmfdScalars hs; hs.done = 0; hs.its = 0;
+        for (int base = 0; base < 100 && !hs.done; base += 10) {
+            for (int it = 0; it < 10; ++it) {
+                for (auto *S : T->slabs) {                        // edge planes of p to the neighbours
+                    const size_t b = (size_t)S->nlines[2] * sizeof(double); const double *pp = S->d_cm + 3 * S->N;
+                    HIPCHK(hipMemcpyAsync(S->d_clo, pp, b, hipMemcpyDeviceToDevice, st));
+                    HIPCHK(hipMemcpyAsync(S->d_chi, pp + (size_t)(S->nz - 1) * S->nlines[2], b, hipMemcpyDeviceToDevice, st));
+                }
+                NFCHK(exchange_planes(T, 0, 0, st));
+                for (int i = 0; i < ns; ++i) {
+                    nf_solver *S = T->slabs[i]; const long N = S->N;
+                    CmfdFaces F; for (int d = 0; d < 3; ++d) { F.Dt[d] = S->d_Dt[d] + g * S->nfc[d]; F.Dh[d] = S->d_Dh[d] + g * S->nfc[d]; }
+                    double *diag = S->d_cm, *pp = diag + 3 * N, *q = diag + 4 * N;
+                    hipLaunchKernelGGL(k_cmfd_matvec, dim3(gN[i]), dim3(256), 0, st, make_geom(S), F, (const double *)diag, (const double *)pp, q, N, (const CmfdScalars *)sc,
+                                       T->d_partials + i * T->slab_cap, S->if_lo ? (const double *)S->d_rlo : (const double *)nullptr,
+                                       S->if_hi ? (const double *)S->d_rhi : (const double *)nullptr);
+                }
+                NFCHK(reduce_logic(1, 1));
+                for (int i = 0; i < ns; ++i) {
+                    nf_solver *S = T->slabs[i]; const long N = S->N;
+                    double *diag = S->d_cm, *x = diag + N, *r = x + N, *pp = r + N, *q = pp + N, *z = q + N;
+                    hipLaunchKernelGGL(k_cmfd_update, dim3(gN[i]), dim3(256), 0, st, (const double *)diag, (const double *)pp, (const double *)q, x, r, z, N, (const CmfdScalars *)sc,
+                                       T->d_partials + i * T->slab_cap, T->partial_stride);
+                }
+                NFCHK(reduce_logic(2, 2));
+                for (int i = 0; i < ns; ++i) {
+                    nf_solver *S = T->slabs[i]; const long N = S->N;
+                    hipLaunchKernelGGL(k_cmfd_pupdate, dim3(gN[i]), dim3(256), 0, st, (const double *)(S->d_cm + 5 * N), S->d_cm + 3 * N, N, (const CmfdScalars *)sc);
+                }
+            }
+            HIPCHK(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        for (auto *S : T->slabs) {
+            S->cmfd_last_its += hs.its;
+            hipLaunchKernelGGL(k_cmfd_correct, dim3((unsigned)((S->N + 255) / 256)), dim3(256), 0, st, (const double *)(S->d_cm + S->N), S->d_raw + (size_t)g * S->nphi, S->N, S->nloc, S->cmfd_relax);
+        }
     }
     HIPCHK(hipGetLastError());
     return NF_OK;
@@ -1893,10 +2020,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     int use_diag = (o->use_diagonal_solver && S0->k == 0 && S0->m == 0) ? 1 : 0;   // flag dropped for order > 0 (:1640-1644)
     if (use_diag) NFCHK(nf_build_diagonal_cache(S0));         // whole team; slabs exchange one edge plane per group
     const bool use_cmfd = o->use_cmfd != 0;
-    if (use_cmfd) {                                               // :1655-1658
-        if (!single) return fail(NF_ERR_UNSUPPORTED, "CMFD is not available on a slab-decomposed mesh");
-        NFCHK(cmfd_initialize(S0));
-    }
+    if (use_cmfd) NFCHK(cmfd_initialize_team(T));                 // :1655-1658
     double keff = T->has_valid_keff ? T->last_keff : 1.0;        // :1662
     T->coarse_outer = 0;
     if (o->use_coarse_init && o->n_coarse_factors > 0) {          // :1665-1670
@@ -1978,7 +2102,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             }
             T->hist_cg.push_back(its); T->last_cg_total += its;
         }
-        if (use_cmfd && it >= 2) NFCHK(cmfd_step(S0, keff, use_diag));   // :1750-1761
+        if (use_cmfd && it >= 2) { if (single) NFCHK(cmfd_step(S0, keff, use_diag)); else NFCHK(cmfd_step_team(T, keff, use_diag)); }   // :1750-1761
         // prod_new, norms (:1766-1779)
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];

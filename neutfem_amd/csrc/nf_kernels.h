@@ -1819,9 +1819,10 @@ __global__ __launch_bounds__(256) void k_cmfd_setup(Geom G, CmfdFaces F, const d
     if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[stride + blockIdx.x] = s1; }
 }
 // q = M p ; partial p.q
+// nb_lo / nb_hi (slabs): the neighbouring slab's edge plane of p across the interface below / above, else nullptr
 __global__ __launch_bounds__(256) void k_cmfd_matvec(Geom G, CmfdFaces F, const double *__restrict__ diag, const double *__restrict__ pp,
                                                      double *__restrict__ q, long N, const CmfdScalars *__restrict__ sc,
-                                                     double *__restrict__ partials)
+                                                     double *__restrict__ partials, const double *__restrict__ nb_lo, const double *__restrict__ nb_hi)
 {
     __shared__ double sred[4];
     if (sc->done) return;
@@ -1838,7 +1839,9 @@ __global__ __launch_bounds__(256) void k_cmfd_matvec(Geom G, CmfdFaces F, const 
             const long fl = cmfd_face(G, d, c[0], c[1], c[2]);
             c[d] += 1; const long fu = cmfd_face(G, d, c[0], c[1], c[2]); c[d] -= 1;
             if (cd > 0) s -= (F.Dt[d][fl] + F.Dh[d][fl]) * A * pp[e - st];
+            else if (d == 2 && nb_lo) s -= (F.Dt[d][fl] + F.Dh[d][fl]) * A * nb_lo[e % nxy];
             if (cd < nd - 1) s -= (F.Dt[d][fu] + F.Dh[d][fu]) * A * pp[e + st];
+            else if (d == 2 && nb_hi) s -= (F.Dt[d][fu] + F.Dh[d][fu]) * A * nb_hi[e % nxy];
         }
         q[e] = s; s0 += pe * s;
     }
@@ -1870,21 +1873,9 @@ __global__ void k_cmfd_pupdate(const double *__restrict__ z, double *__restrict_
     const double beta = sc->beta;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < N; e += gridDim.x * 256L) pp[e] = z[e] + beta * pp[e];
 }
-// second reduction stage + Eigen's conjugate_gradient() scalar logic.  One block of 256 threads.
-// op 0: after setup (rhs2, r.z) ; op 1: after matvec (p.q) ; op 2: after update (|r|^2, r.z)
-__global__ __launch_bounds__(256) void k_cmfd_logic(int op, const double *__restrict__ partials, int cnt, long stride,
-                                                    CmfdScalars *__restrict__ sc)
+// Eigen's conjugate_gradient() scalar logic.  op 0: after setup (rhs2, r.z) ; op 1: after matvec (p.q) ; op 2: after update (|r|^2, r.z)
+__device__ __forceinline__ void cmfd_logic(int op, const double *tot, CmfdScalars *sc)
 {
-    __shared__ double sred[4];
-    if (op != 0 && sc->done) return;
-    double tot[2] = { 0.0, 0.0 };
-    const int nq = op == 1 ? 1 : 2;
-    for (int q = 0; q < nq; ++q) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < cnt; i += 256) s += partials[q * stride + i];
-        tot[q] = block_sum(s, sred);
-    }
-    if (threadIdx.x != 0) return;
     if (op == 0) {
         sc->its = 0; sc->alpha = sc->beta = 0.0;
         const double rhs2 = tot[0];
@@ -1900,6 +1891,40 @@ __global__ __launch_bounds__(256) void k_cmfd_logic(int op, const double *__rest
         sc->absNew = tot[1];
         if (sc->its >= 100) sc->done = 1;
     }
+}
+// second reduction stage + the scalar logic.  One block of 256 threads.
+__global__ __launch_bounds__(256) void k_cmfd_logic(int op, const double *__restrict__ partials, int cnt, long stride,
+                                                    CmfdScalars *__restrict__ sc)
+{
+    __shared__ double sred[4];
+    if (op != 0 && sc->done) return;
+    double tot[2] = { 0.0, 0.0 };
+    const int nq = op == 1 ? 1 : 2;
+    for (int q = 0; q < nq; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < cnt; i += 256) s += partials[q * stride + i];
+        tot[q] = block_sum(s, sred);
+    }
+    if (threadIdx.x != 0) return;
+    cmfd_logic(op, tot, sc);
+}
+// slab teams: the totals come from k_finalize (reduce_only) + the all-reduce over ranks
+__global__ void k_cmfd_logic_tot(int op, const double *__restrict__ red, CmfdScalars *__restrict__ sc)
+{
+    if (op != 0 && sc->done) return;
+    double tot[2] = { red[0], op == 1 ? 0.0 : red[1] };
+    cmfd_logic(op, tot, sc);
+}
+// D-tilde of the interface z faces of a slab (ComputeDtildeCoefficients interior formula, :760-790): the cell on the other side belongs
+// to the neighbouring slab (its D and cell height arrive as planes).  Both slabs evaluate 2 DL DR / (DL dR + DR dL) with the same operands.
+__global__ void k_cmfd_dtilde_iface(const double *__restrict__ D_own, const double *__restrict__ D_nb, const double *__restrict__ h_nb, double h_own,
+                                    double *__restrict__ Dt_plane, long nlines, int own_is_upper)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    const double DL = own_is_upper ? D_nb[i] : D_own[i], DR = own_is_upper ? D_own[i] : D_nb[i];
+    const double dL = own_is_upper ? h_nb[i] : h_own, dR = own_is_upper ? h_own : h_nb[i];
+    Dt_plane[i] = 2.0 * DL * DR / (DL * dR + DR * dL);
 }
 // ratio clamp + relaxation (:994-1014); the correction multiplies every moment of the cell
 __global__ void k_cmfd_correct(const double *__restrict__ x, double *__restrict__ phi, long N, int nloc, double omega)

@@ -46,7 +46,10 @@ def main():
     import time
     t.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)                        # fixed work: 16 fine outers (8 coarse) with tight inner solves
     t0 = time.time()
-    k, n = t.solve_keff(True, [2, 1, 2], use_diag=bool(use_diag)) if not use_diag else t.solve_keff(use_diag=True)
+    if use_diag == 2:                                             # diagonal solver + CMFD: interface D-tilde, halo planes and dots of the PCG across ranks
+        k, n = t.solve_keff(use_diag=True, use_cmfd=True)
+    else:
+        k, n = t.solve_keff(True, [2, 1, 2], use_diag=bool(use_diag)) if not use_diag else t.solve_keff(use_diag=True)
     print(f"rank {rank}: k = {k:.12f} after {n} outers, {t.history()['cg'].sum()} CG iterations, {time.time() - t0:.1f} s", flush=True)
     phi = t.get_phi_local() if rt == 0 else np.concatenate([s.get_phi().reshape(2, -1) for s in t.slabs], axis=1)
     J = t.get_J_local() if (not use_diag and rt == 0) else None                 # collective: the z currents cross slabs

@@ -52,7 +52,7 @@ def _run_ranks(world, args, tmp_path, timeout=200):
     return bad, "\n".join(out)
 
 
-@pytest.mark.parametrize("world,per,use_diag,planes", [(2, 1, 0, 48), (3, 1, 0, 48), (2, 2, 0, 48), (3, 1, 1, 48), (4, 1, 0, 12)])
+@pytest.mark.parametrize("world,per,use_diag,planes", [(2, 1, 0, 48), (3, 1, 0, 48), (2, 2, 0, 48), (3, 1, 1, 48), (4, 1, 0, 12), (3, 1, 2, 16)])
 def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes, tmp_path):
     """planes = 48: coarse slabs of 24 planes need one separator sweep; planes = 12: the fine slabs themselves are thin"""
     out = str(tmp_path / "res.npz")
@@ -65,7 +65,7 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     assert rel_l2(res["y"].ravel(), o.schur_apply(1, res["x"].ravel())) < 1e-12
     assert np.ptp(res["k"]) == 0.0 and np.ptp(res["n"]) == 0          # every rank returns the same k and outer count
     s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)       # the same fixed work, undivided
-    ks, ns = s.solve_keff(use_diag=True) if use_diag else s.solve_keff(True, [2, 1, 2])
+    ks, ns = (s.solve_keff(use_diag=True, use_cmfd=use_diag == 2)) if use_diag else s.solve_keff(True, [2, 1, 2])
     assert int(res["n"][0]) == ns == 16
     assert abs(res["k"][0] - ks) / ks < 1e-8
     assert rel_l2(res["phi"].ravel(), s.get_phi().ravel()) < 1e-6
