@@ -27,7 +27,8 @@ def main():
     allp = split_planes(nz, world * per)
     mine = allp[rank * per:(rank + 1) * per]
     k0, k1 = mine[0][0], mine[-1][1]
-    t = capi.HipTeam(rt, rt, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], mine, device=0, below=rank > 0, above=rank < world - 1)
+    dev = rank if os.environ.get("NEUTFEM_WORKER_RANK_IS_DEVICE") else 0      # real RCCL: one GPU per rank; stand-in transport: all ranks on GPU 0
+    t = capi.HipTeam(rt, rt, 2, inp["x_breaks"], inp["y_breaks"], inp["z_breaks"], mine, device=dev, below=rank > 0, above=rank < world - 1)
     t.set_linear_solver(6)
     for a, ty in zip(inp["bc_attr"], inp["bc_type"]):
         t.set_bc(int(a), int(ty))

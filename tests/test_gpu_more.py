@@ -19,11 +19,13 @@ def test_checkerboard_8_groups_with_upscatter():
     from neutfem_amd import cases
     inp = _from_case(cases.synthetic_checkerboard(24, 8))
     o, s = make_oracle(inp), make_hip(inp)
-    tol = (1e-9, 1e-9, 1e-9, 600, 2000)
+    # the 1e-8 flux bar needs both runs converged beyond it: a power iteration stopped at dphi < tol is only converged to about
+    # tol / (1 - dominance ratio), ~50 tol here, so the stop tests sit at 1e-11 (at 1e-9 the two runs agreed to 5e-8, no better)
+    tol = (1e-11, 1e-11, 1e-11, 1200, 3000)
     o.set_tol(*tol); s.set_tol(*tol)
     ko = o.SolveKeff(True, [2, 2, 2]); ks, n = s.solve_keff(True, [2, 2, 2])
-    assert abs(ks - ko) / ko < 1e-9 and abs(n - o.info("last_outer")) <= 1
-    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 5e-8
+    assert abs(ks - ko) / ko < 1e-10 and abs(n - o.info("last_outer")) <= 2
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8
     s.close()
 
 

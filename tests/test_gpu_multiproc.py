@@ -31,13 +31,13 @@ def _env():
     return e
 
 
-def _run_ranks(world, args, tmp_path, timeout=200):
+def _run_ranks(world, args, tmp_path, timeout=200, env=None):
     """start `world` workers, fail fast (with every rank's output) if one exits non-zero or the run exceeds `timeout` s"""
     import time
     port = str(_free_port())
     logs = [open(str(tmp_path / f"rank{r}.log"), "w+") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world), port] + [str(a) for a in args],
-                              env=_env(), stdout=logs[r], stderr=subprocess.STDOUT) for r in range(world)]
+                              env=env or _env(), stdout=logs[r], stderr=subprocess.STDOUT) for r in range(world)]
     t0 = time.time(); bad = None
     while any(p.poll() is None for p in procs):
         if any(p.poll() not in (None, 0) for p in procs): bad = "a rank failed"; break
@@ -147,3 +147,25 @@ def test_bench_json_contract_single_rank():
     assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0 and isinstance(cb["sample"], str)
     assert d["parity"]["pcm"] < 1.0 and d["parity"]["flux_rel_l2"] < 1e-8
     assert len(d["other_configs"]) == 4 and all(c["pcm_vs_oracle"] < 1.0 for c in d["other_configs"])
+
+
+def test_two_ranks_over_the_real_rccl(tmp_path):
+    """The same worker over the REAL librccl, one GPU per rank: needs a box with at least two GPUs (the one-GPU test boxes skip it;
+    RCCL refuses two ranks on one device).  Exercises what the stand-in transport cannot: grouped ncclSend / ncclRecv on the comm stream
+    next to ncclAllReduce on the solver's stream of ONE communicator, and the order of the collective calls across processes."""
+    from neutfem_amd import capi
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs: real RCCL has one rank per device")
+    e = dict(os.environ); e.pop("NEUTFEM_RCCL_LIB", None); e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"; e["NEUTFEM_WORKER_RANK_IS_DEVICE"] = "1"
+    out = str(tmp_path / "res.npz")
+    bad, logs = _run_ranks(2, [out, 1, 0, 48], tmp_path, timeout=300, env=e)
+    assert bad is None, bad + "\n" + logs
+    res = np.load(out)
+    inp = synthetic_inputs(10, 8, 96, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
+    o = make_oracle(inp)
+    assert rel_l2(res["y"].ravel(), o.schur_apply(1, res["x"].ravel())) < 1e-12
+    s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)
+    ks, ns = s.solve_keff(True, [2, 1, 2])
+    assert int(res["n"][0]) == ns == 16 and abs(res["k"][0] - ks) / ks < 1e-8
+    assert rel_l2(res["phi"].ravel(), s.get_phi().ravel()) < 1e-6
+    s.close()

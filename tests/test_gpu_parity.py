@@ -310,3 +310,38 @@ def test_solve_adjoint(name, rt):
     np.testing.assert_allclose(s.history()["k"], o.history()["k"], rtol=1e-8)
     assert rel_l2(s.get_phi_adj().ravel(), o.phi_adj_dofs().ravel()) < 1e-7
     s.close()
+
+
+@pytest.mark.parametrize("fuse3", [1, 0])
+def test_iaea3d_128cube_golden(fuse3):
+    """The benchmark workload at 128^3 (2.1 M cells, the generator bench.py uses at 256^3) against the oracle's golden run
+    (tests/golden/make_golden_128cube.py, ~45 min of one core): full-wavefront x lines, 16-segment y / z lines, ~1500 blocks per pass
+    -- a FULL solve at a size where the chip is busy, on both CG shapes (fuse3 = 1: k_apply3, two launches per iteration;
+    0: the four-launch path the 256^3 bench takes).
+      fixed   5 outers, CG to 1e-10, no coarse start: the iteration path is pinned, so k-history and flux are compared tightly
+      driver  the reference drivers' settings (1e-5 / 1e-4, coarse start): k within 1 pcm, same outer count +-1; the flux bar is the
+              IAEA-3D one (2 tol_flux: void cells make the reference's CG rounding-sensitive)"""
+    import json
+    from neutfem_amd import cases
+    from neutfem_amd.capi import HipSolver
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden_iaea3d_128cube.json")) as f:
+        gold = json.load(f)["runs"]
+    c = cases.iaea3d_resampled(128)
+    s = HipSolver(0, 0, c["ng"], c["x_breaks"], c["y_breaks"], c["z_breaks"]); s.set_linear_solver(6)
+    for a, t in c["bc"]:
+        s.set_bc(a, t)
+    s.upload_xs(c["D"], c["SigR"], c["NSF"], c["Chi"], c["SigS"]); s.build()
+    s.set_option("cg_fuse3", fuse3)
+    r = gold["fixed"]
+    s.set_tol(*r["tol"]); k, n = s.solve_keff()
+    assert n == r["n_outer"] == 5
+    np.testing.assert_allclose(s.history()["k"], r["k_hist"], rtol=2e-9)
+    cg_g, cg_o = s.history()["cg"].sum(), np.sum(r["cg"])
+    assert abs(cg_g - cg_o) <= 0.05 * cg_o, (cg_g, cg_o)
+    phi = s.get_phi().ravel()
+    assert rel_l2(phi[::r["phi_stride"]], r["phi_samples"]) < 1e-8
+    r = gold["driver"]
+    s.reset_flux(); s.set_tol(*r["tol"]); k, n = s.solve_keff(True, r["factors"])
+    assert abs(k - r["keff"]) / r["keff"] < PCM and abs(n - r["n_outer"]) <= 1
+    assert rel_l2(s.get_phi().ravel()[::r["phi_stride"]], r["phi_samples"]) < 2.0 * r["tol"][1]
+    s.close()

@@ -243,8 +243,34 @@ def test_oracle_converges_to_the_drivers_power_tables(name, kref, final_pct, fin
         nm = pv.shape[0] // na
         F = pv.reshape(na, nm, na, nm).sum(axis=1).sum(axis=2); F = tab["normalisation"] * F / F.sum()
         errs.append(np.nanmax(np.abs(100.0 * (ref - F) / ref))); pcms.append(abs(1e5 * (1 / kref - 1 / k)))
-    assert errs[0] > errs[1] > errs[2] and pcms[0] > pcms[1] > pcms[2]
-    assert errs[2] < final_pct and pcms[2] < final_pcm
+    assert errs[0] > errs[1] > errs[2] and errs[2] < final_pct     # assembly powers: monotone onto the published table
+    assert pcms[2] < final_pcm                                     # k: see test_richardson_limits_against_kref for what k_ref pins
+
+
+def test_richardson_limits_against_kref():
+    """What the literature k_ref scalars of the drivers pin (oracle/sweep_kref.py, table in tests/golden/kref_richardson.json): for
+    IAEA-2D, BIBLIS and KOEBERG the oracle was run at 1 ... 16 cells per assembly for RT0-P0, RT1-P1 and RT2-P2 and the h -> 0 limit of
+    every order Richardson-extrapolated from its three finest meshes.  (i) The three orders -- which share the reference's formulas for
+    their local matrices and nothing else -- extrapolate to the same limit within 0.6 pcm; (ii) that limit sits +7.0 pcm (IAEA-2D), +0.7
+    (BIBLIS) and +1.1 (KOEBERG) from the drivers' k_ref: the benchmarks' own uncertainty, not a convergence onto the scalar; (iii) the
+    committed table is what the oracle computes today (cheap entries recomputed here)."""
+    import json, os, sys
+    tab = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kref_richardson.json")))
+    expected = {"iaea2d": (7.0, 0.5), "biblis2d": (0.7, 0.5), "koeberg2d": (1.1, 0.3)}
+    for name, (off, slack) in expected.items():
+        lim = [v["limit_pcm_vs_kref"] for v in tab["cases"][name]["orders"].values()]
+        assert len(lim) == 3 and all(l is not None for l in lim)
+        assert max(lim) - min(lim) < 0.6, (name, lim)
+        assert all(abs(l - off) <= slack for l in lim), (name, lim)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sweep_kref", os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "sweep_kref.py"))
+    sweep = importlib.util.module_from_spec(spec); sys.path.pop(0)
+    spec.loader.exec_module(sweep)
+    for name, rt, m in (("iaea2d", 0, 2), ("iaea2d", 1, 1), ("iaea2d", 2, 1), ("biblis2d", 1, 1), ("koeberg2d", 0, 2)):
+        row = tab["cases"][name]["orders"][f"RT{rt}-P{rt}"]
+        k = sweep.run((name, rt, m))[3]
+        assert abs(k - row["keff"][row["cells_per_assembly"].index(m)]) < 1e-9, (name, rt, m)
 
 
 def test_reference_quirks():
