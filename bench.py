@@ -245,11 +245,14 @@ def main():
     # cell in a committed profile; `traffic_source` says which one, so a stale profile is visible.  null when no profile matches the run.
     traffic, traffic_source = None, None
     try:
-        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_256cube.json"))[-1]
+        import re
+        def _tag(fn):                                               # r02_a_... -> (2, "a"); r01_... -> (1, "")
+            m = re.match(r"r(\d+)_(?:([a-z])_)?", fn)
+            return (int(m.group(1)), m.group(2) or "") if m else (0, "")
+        prof = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_256cube.json")), key=_tag)[-1]
         with open(os.path.join(ROOT, "profiles", prof)) as f:
             pj = json.load(f)
         pmc = pj["kernels"]
-        import re
         pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_s<\d+, 1,", "schur_z": r"k_schur_s<\d+, 2,", "schur_apply": r"k_apply3<"}[dom["name"]]
         hits = [k for k in pmc if re.match(pat, k)]
         key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None

@@ -118,7 +118,9 @@ int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_ou
 /* CMFD acceleration (src/NeutFEM.cpp:662-1017, include/NeutFEM.hpp:119-143,232-235): NeutFEM::InitializeCMFD
  * (D-tilde for every direction, D-hat = 0; idempotent until the next nf_build), SetCMFDRelaxation, and a probe that
  * downloads D-tilde / D-hat of (group, direction) in the reference's face numbering (either pointer may be NULL).
- * The correction itself runs inside nf_solve_keff when opts.use_cmfd is set.  Undivided meshes only. */
+ * The correction itself runs inside nf_solve_keff when opts.use_cmfd is set.  On a slab team nf_initialize_cmfd is collective
+ * (the D-tilde of an interface z face needs the neighbouring slab's edge cells) and the PCG exchanges one plane per interface
+ * and iteration. */
 int nf_initialize_cmfd(nf_handle h);
 int nf_set_cmfd_relaxation(nf_handle h, double omega);
 int nf_get_cmfd_coefficients(nf_handle h, int g, int dir, double *dtilde_host, double *dhat_host);
@@ -160,14 +162,24 @@ int nf_time_schur_apply(nf_handle h, int g, int reps, double *avg_ms);
  * roofline is reported against the 8 TB/s spec and against this measured figure */
 int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
 
-/* tuning knobs (no reference counterpart): "s_tx" lanes per block row, "s_seg" cells per register segment and
- * "s_pair" (0/1: two columns per thread, 16-byte accesses) of the y/z line kernels; "cg_batch" CG iterations
- * launched between host checks of the device-side stop flag (0 = automatic); "cg_fuse" (default 1) folds the CG vector
- * updates x += alpha p, p = r + beta p into the next x pass on undivided RT0-P0 meshes (bit-identical iterates);
- * "xcd" (default 0) gives each XCD one contiguous range of y/z tiles (measured: no gain at 256^3);
- * "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
- * "cg_lean" (default 1) drops the two finalize launches of a CG iteration on undivided meshes (consumer-side reduction,
- * bit-identical; meshes of at most "cg_lean_max_cells" cells, default 4 Mi), "cg_lean_grid" = blocks of its residual update. */
+/* tuning knobs (no reference counterpart):
+ *   "s_tx" (0 auto, 8, 16, 32, 64) columns per block and "s_seg" (0 auto, 4, 8, 16, 32) cells per register segment of the y/z line
+ *   kernels; "s_wsmin" segments per line from which whole wavefronts scan the segment summaries (default 64);
+ *   "xcd" (default 0) gives each XCD one contiguous range of y/z tiles (measured: no gain);
+ *   "cg_batch" CG iterations launched between host checks of the device-side stop flag (0 = automatic);
+ *   "cg_fuse" (default 1) folds x += alpha p, p = r + beta p into the next pass that reads p (bit-identical iterates);
+ *   "cg_lean" (default 1) lets the consumer of a reduction derive the CG scalars itself: no finalize launches on undivided meshes of at
+ *   most "cg_lean_max_cells" cells (default 4 Mi; "cg_lean_grid" = blocks of the residual update), no k_cg_logic launches on slab teams;
+ *   "cg_fuse3" (default 1) runs the x, y and z passes of an apply as ONE launch (two launches per CG iteration) on undivided meshes of
+ *   at most "cg_fuse3_max_cells" cells (default 4 Mi);
+ *   "resident" (default 1) runs the whole SolveKeff of an undivided mesh with at most "resident_max_dofs" flux DOFs per group (default
+ *   2500) in one workgroup and one launch; "resident_lds" (default 1) keeps its CG vectors and factors in LDS as far as they fit;
+ *   "direct_max_dofs" (default 2048, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
+ *   CG to 1e-14 stands in (nf_info "direct_standin_unconverged" counts group solves that did not get there);
+ *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
+ *   "sep_fold" (default 1): slab teams form the separator values inside the accumulation pass of the z lines (no k_separators launch).
+ * nf_info keys beyond the mesh sizes: "last_path" (0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel),
+ * "last_direct" (0 CG as configured, 1 dense S^-1, 2 CG to 1e-14 standing in). */
 int nf_set_option(nf_handle h, const char *key, long value);
 
 /* raw device-memory helpers so callers without torch can drive the *_dev entry points */
