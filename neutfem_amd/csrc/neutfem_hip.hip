@@ -856,8 +856,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     int NSEG = (n + SEG - 1) / SEG;
     if (NSEG > 128) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit", n);
     int TX = T->opt_s_tx ? T->opt_s_tx : 64;
-    while (TX > 8 && TX * NSEG > 1024) TX >>= 1;
-    if (TX * NSEG > 1024) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than 1024 threads per block", n);
+    const int tmax = zmode != 0 ? 512 : 1024;                     // slab variants: 512 threads (register budget, see k_schur_s)
+    while (TX > 8 && TX * NSEG > tmax) TX >>= 1;
+    if (TX * NSEG > tmax) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than %d threads per block", n, tmax);
     while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;                   // narrow meshes
     const ModeTab mt = mode_tab(S, d);
     dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter, (unsigned)mt.n), block((unsigned)(TX * NSEG));
@@ -869,7 +870,8 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 16) * sizeof(double);
     const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
     const CgLean lz = (zmode == 1 && S->nloc == 1 && fz.p) ? S->lean_z1 : CgLean{ nullptr, nullptr, 0, 0, 0 };
-#define NF_S(SEGV, DIRV, SLABV, NBV) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz)
+#define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); } while (0)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
         else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
     if (zmode != 0) {

