@@ -861,7 +861,8 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     if (TX * NSEG > tmax) return fail(NF_ERR_UNSUPPORTED, "line length %d needs more than %d threads per block", n, tmax);
     while (TX > 8 && TX / 2 >= S->nx) TX >>= 1;                   // narrow meshes
     const ModeTab mt = mode_tab(S, d);
-    dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter, (unsigned)mt.n), block((unsigned)(TX * NSEG));
+    // whole wavefronts: the reductions use data-parallel-primitive moves and read lane 63 (threads beyond TX * NSEG only keep the barriers company)
+    dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter, (unsigned)mt.n), block((unsigned)((TX * NSEG + 63) / 64 * 64));
     if (nparts) *nparts = (int)(grid.x * grid.y * grid.z);
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;

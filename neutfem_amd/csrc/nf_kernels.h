@@ -33,11 +33,26 @@ struct CgScalars {
     double rr2[2]; int its2[2];
 };
 
+// Sum over the 64 lanes of a wavefront, result in every lane.  Data-parallel-primitive moves (row_shr 1/2/4/8 inside each row of
+// 16 lanes, then row_bcast 15 and 31 across rows) instead of ds_bpermute shuffles: six dependent steps of a few cycles each where
+// the LDS crossbar costs ~100 cycles per step -- the reductions sit on the critical path of every latency-bound kernel here.
+// Fixed order (deterministic); out-of-row sources read as zero (bound_ctrl).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __hiloint2double(hi, lo);          // lanes outside ROW_MASK receive 0 (old = 0, bound_ctrl): v + 0
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = dpp_add<0x111, 0xF>(v);                   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);                   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);                   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);                   // row_shr:8  -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xA>(v);                   // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold rows 0+1 / 2+3
+    v = dpp_add<0x143, 0xC>(v);                   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // fixed-order block sum; result valid in thread 0.  sred: >= blockDim/64 doubles of LDS.
@@ -151,15 +166,24 @@ __device__ __forceinline__ double strided_total(const double *p, int cnt, double
     return s;
 }
 // FIN_RR for the iteration of parity lean.par; returns true when the solve stops here.  *beta_out is valid when it continues.
-__device__ __forceinline__ bool lean_rr_step(const CgLean &lean, bool writer, double *sred, double *beta_out)
+// The scalars of the previous iteration are loaded up front (LeanPre), so that a kernel can have them -- and its own tile loads -- in
+// flight while the partial sums are reduced, instead of paying one memory round trip after the other.
+struct LeanPre { double rr_old, tol_sq; int its_old, maxit; };
+__device__ __forceinline__ LeanPre lean_preload(const CgLean &lean)
+{
+    const CgScalars *st = lean.st; const int qo = lean.par ^ 1;
+    LeanPre p; p.rr_old = st->rr2[qo]; p.tol_sq = st->tol_sq; p.its_old = st->its2[qo]; p.maxit = st->maxit;
+    return p;
+}
+__device__ __forceinline__ bool lean_rr_step(const CgLean &lean, const LeanPre &pre, bool writer, double *sred, double *beta_out)
 {
     CgScalars *st = lean.st;
-    const int q = lean.par, qo = q ^ 1;
+    const int q = lean.par;
     const double rr_new = lean_total(lean, sred);
-    const double rr_old = st->rr2[qo];
-    const int its_new = st->its2[qo] + 1;
-    const bool conv = rr_new < st->tol_sq;
-    const bool stop = conv || its_new >= st->maxit;
+    const double rr_old = pre.rr_old;
+    const int its_new = pre.its_old + 1;
+    const bool conv = rr_new < pre.tol_sq;
+    const bool stop = conv || its_new >= pre.maxit;
     const double beta = rr_new / rr_old;
     if (writer) {
         st->rr2[q] = rr_new; st->its2[q] = its_new;
@@ -170,6 +194,12 @@ __device__ __forceinline__ bool lean_rr_step(const CgLean &lean, bool writer, do
     *beta_out = beta;
     return stop;
 }
+__device__ __forceinline__ bool lean_rr_step(const CgLean &lean, bool writer, double *sred, double *beta_out)
+{
+    return lean_rr_step(lean, lean_preload(lean), writer, sred, beta_out);
+}
+// what a direction pass does between issuing its loads and using them (nothing, by default)
+struct NoMid { __device__ __forceinline__ bool operator()(double &, double &) const { return false; } };
 __global__ __launch_bounds__(256) void k_cg_lean_rr(CgLean lean)
 {
     __shared__ double sred[4];
@@ -475,10 +505,10 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
 struct CgFuse { double *p; const double *r; double *xsol; double *pout; };
 
 // One wave-task of the x pass: 64/LPL lines, lane = (line of the task, position in the line).  Returns the lane's share of x.y.
-template <int K, int NCH, bool VEC, int NB>
+template <int K, int NCH, bool VEC, int NB, class Mid = NoMid>
 __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2, int first,
-                                               long task, int lane, bool active, bool fuse, double f_alpha, double f_beta, const CgFuse &fz)
+                                               long task, int lane, bool active, bool fuse, double f_alpha, double f_beta, const CgFuse &fz, Mid mid = Mid())
 {
     static_assert(K == 2, "two cells per lane and chunk");
     const int LPL = 1 << lpl_log2, LPW = 64 >> lpl_log2;
@@ -488,7 +518,9 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
     const long base = lv ? line * nx : 0;
     const int iy = lv ? (int)(line % ny) : 0, iz = lv ? (int)(line / ny) : 0;
     double xm[NB + 1][NCH][K], yo[NB + 1][NCH][K], Ls[NCH][K], Rs[NCH][K], w[NCH][K], xL[NCH][K], xR[NCH][K], ic[NCH][K];
+    double rq[NB + 1][NCH][K], sq[NB + 1][NCH][K], dq[NB > 0 ? NCH : 1][K];   // fused variants: r and x_sol of the same cells; D (1 / c_e)
     double *pw = fz.pout ? fz.pout : fz.p;
+    // ---- loads only (every load of the pass is in flight before `mid` runs and before the first value is used)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
@@ -499,16 +531,26 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
         for (int q = 0; q <= NB; ++q) {
             ld2(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
             ld2(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
+            if (fuse) {                                          // ma.x[q] points into p: the same offset addresses r and x_sol
+                const long mo = (ma.x[q] - fz.p) + base + c0;
+                ld2(fz.r, mo, ok, VEC, rq[q][ch][0], rq[q][ch][1], ok2);
+                ld2(fz.xsol, mo, ok, VEC, sq[q][ch][0], sq[q][ch][1], ok2);
+            }
         }
+        if (NB > 0) ld2(ma.D, base + c0, ok, VEC, dq[NB > 0 ? ch : 0][0], dq[NB > 0 ? ch : 0][1], ok2);
+    }
+    if (mid(f_alpha, f_beta)) return 0.0;
+    // ---- the deferred CG update of these cells, then the face values
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = (ch * LPL + li) * K;
+        const bool ok = lv && c0 < nx, ok2 = lv && c0 + 1 < nx;
         if (fuse) {
 #pragma unroll
-            for (int q = 0; q <= NB; ++q) {                      // ma.x[q] points into p: the same offset addresses r and x_sol
+            for (int q = 0; q <= NB; ++q) {
                 const long mo = (ma.x[q] - fz.p) + base + c0;
-                double r0, r1, s0, s1;
-                ld2(fz.r, mo, ok, VEC, r0, r1, ok2);
-                ld2(fz.xsol, mo, ok, VEC, s0, s1, ok2);
-                s0 = fma(f_alpha, xm[q][ch][0], s0); s1 = fma(f_alpha, xm[q][ch][1], s1);
-                xm[q][ch][0] = fma(f_beta, xm[q][ch][0], r0); xm[q][ch][1] = fma(f_beta, xm[q][ch][1], r1);
+                const double s0 = fma(f_alpha, xm[q][ch][0], sq[q][ch][0]), s1 = fma(f_alpha, xm[q][ch][1], sq[q][ch][1]);
+                xm[q][ch][0] = fma(f_beta, xm[q][ch][0], rq[q][ch][0]); xm[q][ch][1] = fma(f_beta, xm[q][ch][1], rq[q][ch][1]);
                 if (VEC) {
                     if (ok) { *reinterpret_cast<double2 *>(fz.xsol + mo) = make_double2(s0, s1);
                               *reinterpret_cast<double2 *>(pw + mo) = make_double2(xm[q][ch][0], xm[q][ch][1]); }
@@ -523,8 +565,7 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
             double pl = 0.0, pr = 0.0;
             ic[ch][j] = 0.0;
             if (NB > 0) {
-                double dd0, dd1; ld2(ma.D, base + c0, ok, VEC, dd0, dd1, ok2);
-                const double dd = j == 0 ? dd0 : dd1;
+                const double dd = dq[NB > 0 ? ch : 0][j];
                 const bool okj = j == 0 ? ok : ok2;
                 ic[ch][j] = okj ? dd / geom_factor(G, 0, c0 + j, iy, iz) : 0.0;      // 1 / c_e
 #pragma unroll
@@ -621,16 +662,21 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
 {
     __shared__ double sred[4];
     if (cg && cg->done) return;
-    bool lean_fuse = false; double lean_beta = 0.0;
-    if (lean.st && !lean.first) {                               // lean CG: this pass consumes the |r|^2 partials (FIN_RR)
-        if (lean_rr_step(lean, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &lean_beta)) return;
-        lean_fuse = true;
-    }
     const ModeArgs ma = select_mode(ma0, mt, blockIdx.y, NB + 1);
-    const bool fuse = fz.p != nullptr && (lean.st ? lean_fuse : cg->its > 0);
-    const double f_alpha = fuse ? cg->alpha : 0.0, f_beta = fuse ? (lean.st ? lean_beta : cg->beta) : 0.0;
+    const bool lean_on = lean.st && !lean.first;                 // lean CG: this pass consumes the |r|^2 partials (FIN_RR)
+    const bool fuse = fz.p != nullptr && (lean.st ? lean_on : cg->its > 0);
+    const double alpha0 = fuse ? cg->alpha : 0.0, beta0 = (fuse && !lean.st) ? cg->beta : 0.0;
+    LeanPre pre = { 0.0, 0.0, 0, 0 };
+    if (lean_on) pre = lean_preload(lean);
+    bool stopped = false;
+    auto mid = [&](double &fa, double &fb) -> bool {             // runs with the pass's loads in flight
+        (void)fa;
+        if (lean_on) stopped = lean_rr_step(lean, pre, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &fb);
+        return stopped;
+    };
     const double dot = schur_x_task<K, NCH, VEC, NB>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first, (long)blockIdx.x * 4 + (threadIdx.x >> 6),
-                                                     threadIdx.x & 63, true, fuse, f_alpha, f_beta, fz);
+                                                     threadIdx.x & 63, true, fuse, alpha0, beta0, fz, mid);
+    if (stopped) return;                                         // decided inside, the same in every block: nothing to reduce
     if (last && partials) {
         const double s = block_sum(dot, sred);
         if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
@@ -667,12 +713,12 @@ struct SlabArgs {
 // r + beta x, formed on the fly (see CgFuse).  Returns the thread's share of x.y.
 // SF (slab variants): the instantiation that can carry the fused CG update (r and x_sol of the cells in registers: 160 instead of
 // 128 VGPRs); the accumulation / emit passes use the one without
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false>
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, class Mid = NoMid>
 __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                                                unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
                                                const SlabArgs &sa, const CgFuse &fz, bool fuse, bool fro, double f_alpha, double f_beta, bool acc,
-                                               long long *stamp = nullptr)
+                                               long long *stamp = nullptr, Mid mid = Mid())
 {
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     double *__restrict__ y = ma.y[0];
@@ -760,6 +806,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             if (i < SEG) Dv[i] = ok ? ma.D[a] : 0.0;
         }
     }
+    double dinv_s = 0.0;
+    if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
+    NF_STAMP(stamp, 3);
+    if (mid(f_alpha, f_beta)) return 0.0;                        // e.g. the reduction that yields beta: runs with the loads above in flight
     // ---- arithmetic on the loaded values (cells outside the line hold zeros throughout)
 #pragma unroll
     for (int i = 0; i <= SEG; ++i) {
@@ -788,8 +838,6 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 #pragma unroll
         for (int i = 0; i < SEG; ++i) if (valid && c0 + i < n) fz.xsol[base + (long)(c0 + i) * sl] = sv[(SLAB && SF) ? i : 0];
     }
-    double dinv_s = 0.0;
-    if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
     double t[NB > 0 ? SEG : 1];                                  // NB == 0: t_i = xv_i - xv_{i+1} is recomputed where needed (registers)
     double P = 1.0, lz = 0.0;
     double xL0 = xv[0];                                          // xL of this segment's first cell
@@ -1075,17 +1123,24 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
     long long st_r0 = 0, st_0 = 0, st_1 = 0;
     if (stamp) { st_r0 = (long long)__builtin_amdgcn_s_memrealtime(); st_0 = (long long)__builtin_readcyclecounter(); }
 #endif
-    if (cg->done) return;
+    // scalars of the previous iteration: requested here, consumed inside `mid` -- the pass's own loads go out in between, so the
+    // block pays ONE memory round trip for flags, scalars, partial sums and tile data instead of four in a row
+    const int done0 = cg->done;
+    const bool fuse = !lean.first;
+    const double alpha0 = fuse ? cg->alpha : 0.0;
+    LeanPre pre = { 0.0, 0.0, 0, 0 };
+    if (fuse) pre = lean_preload(lean);
+    bool stopped = false;
+    auto mid = [&](double &fa, double &fb) -> bool {
+        (void)fa;
+        if (done0) { stopped = true; return true; }
 #ifdef NF_STAMPS
-    if (stamp) st_1 = (long long)__builtin_readcyclecounter();
+        if (stamp) st_1 = (long long)__builtin_readcyclecounter();
 #endif
-    bool fuse = false; double f_beta = 0.0;
-    if (!lean.first) {                                           // FIN_RR of the previous iteration: beta, stop tests
-        if (lean_rr_step(lean, blockIdx.x == 0 && threadIdx.x == 0, sred, &f_beta)) return;
-        fuse = true;
-    }
-    const double f_alpha = fuse ? cg->alpha : 0.0;
-    NF_STAMP(stamp, 2);
+        if (fuse) stopped = lean_rr_step(lean, pre, blockIdx.x == 0 && threadIdx.x == 0, sred, &fb);   // FIN_RR of the previous iteration: beta, stop tests
+        NF_STAMP(stamp, 2);
+        return stopped;
+    };
     const unsigned b = blockIdx.x;
     double dot = 0.0;
     if (b < (unsigned)A.nbx) {
@@ -1095,7 +1150,7 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
         const bool active = mode < mtx.n;
         const ModeArgs ma = select_mode(max0, mtx, active ? mode : 0, NB + 1);
         dot = schur_x_task<2, NCH, VEC, NB>(ma, G, Lx, DRx, D0x, nx, ny, nlines_x, A.lpl_log2, 1, gt % A.ntask_x, threadIdx.x & 63, active,
-                                            fuse, f_alpha, f_beta, fz);
+                                            fuse, alpha0, 0.0, fz, mid);
     } else {
         const int r = b < (unsigned)(A.nbx + A.nby) ? 0 : 1;
         const unsigned t = b - A.nbx - (r ? A.nby : 0);
@@ -1104,13 +1159,14 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
         if (r == 0) {
             const ModeArgs ma = select_mode(may0, mty, bz, NB + 1);
             dot = schur_s_tile<SEG, 1, false, NB>(ma, G, Ly, DRy, D0y, A.n[0], A.sl[0], A.ostride[0], nx, A.TX[0], A.NSEG[0], bx, by, bz, A.gy[0],
-                                                  (int)threadIdx.x, true, sm, sa, fz, false, fuse, f_alpha, f_beta, false, stamp);
+                                                  (int)threadIdx.x, true, sm, sa, fz, false, fuse, alpha0, 0.0, false, stamp, mid);
         } else {
             const ModeArgs ma = select_mode(maz0, mtz, bz, NB + 1);
             dot = schur_s_tile<SEG, 2, false, NB>(ma, G, Lz, DRz, D0z, A.n[1], A.sl[1], A.ostride[1], nx, A.TX[1], A.NSEG[1], bx, by, bz, A.gy[1],
-                                                  (int)threadIdx.x, true, sm, sa, fz, false, fuse, f_alpha, f_beta, false, stamp);
+                                                  (int)threadIdx.x, true, sm, sa, fz, false, fuse, alpha0, 0.0, false, stamp, mid);
         }
     }
+    if (stopped) return;
     NF_STAMP(stamp, 8);
     const double sdot = block_sum(dot, sred);
     if (threadIdx.x == 0) partials[b] = sdot;
@@ -1125,14 +1181,22 @@ __global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, con
                                                      double *__restrict__ partials, CgLean lean)
 {
     __shared__ double sred[4];
-    if (cg->done) return;
+    // flags, |r|^2 of this iteration and the first trip's vector entries are requested before the reduction of the p.q partials
+    // (one memory round trip instead of three in a row; on the latency-bound meshes this kernel is one trip long)
+    const int done0 = cg->done;
+    const double rr_cur = lean.st->rr2[lean.par];
+    const long i0 = blockIdx.x * 256L + threadIdx.x;
+    double r0 = 0.0, q0 = 0.0;
+    if (i0 < n) { r0 = r[i0]; q0 = qx[i0]; if (qy) q0 += qy[i0]; if (qz) q0 += qz[i0]; }
+    if (done0) return;
     const double pq = strided_total(lean.partials, lean.count, sred);
     const bool brk = fabs(pq) < 1e-30;
-    const double alpha = brk ? 0.0 : lean.st->rr2[lean.par] / pq;
+    const double alpha = brk ? 0.0 : rr_cur / pq;
     if (blockIdx.x == 0 && threadIdx.x == 0) { lean.st->pAp = pq; lean.st->pend = 0; if (brk) lean.st->done = 1; else lean.st->alpha = alpha; }
     if (brk) return;
     double s = 0.0;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    if (i0 < n) { const double rn = r0 - alpha * q0; r[i0] = rn; s += rn * rn; }
+    for (long i = i0 + gridDim.x * 256L; i < n; i += gridDim.x * 256L) {
         double q = qx[i];
         if (qy) q += qy[i];
         if (qz) q += qz[i];
