@@ -122,7 +122,7 @@ struct nf_team {
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
     int opt_fuse3 = 1; long fuse3_max_cells = 4L << 20;   // fused-direction CG (two launches per iteration) up to this many cells
-    int opt_resident = 1, opt_resident_lds = 1; long resident_max_dofs = 2500;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
+    int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, last_resident_serial = 0; long resident_max_dofs = 2500;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
     long direct_max_dofs = 2048;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group
@@ -535,7 +535,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("last_path", T->last_path); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
+    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
 #undef K
     return -1;
 }
@@ -1558,7 +1558,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
         CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
-        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->resident_max_dofs = T->resident_max_dofs;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->resident_max_dofs = T->resident_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
     double kc = 1.0; int nout = 0;
@@ -1879,7 +1879,7 @@ static int solve_keff_diag_device(nf_team *T, const nf_keff_opts *o, double keff
     hipStream_t st = T->stream;
     if (!S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NT)); NFCHK(dalloc(&S->d_p1, (size_t)NT)); }
     if (!T->d_ost) NFCHK(dalloc(&T->d_ost, 1));
-    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer)); T->hist_cap = o->max_outer; }
+    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer + 8)); T->hist_cap = o->max_outer; }
     double *hk = T->d_hist, *hdk = hk + T->hist_cap, *hdp = hdk + T->hist_cap;
     OuterState h; memset(&h, 0, sizeof h);
     h.keff = keff0; h.tol_keff = o->tol_keff; h.tol_flux = o->tol_flux; h.max_outer = o->max_outer;
@@ -1964,7 +1964,10 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     A.keff0 = keff0; A.tol_keff = o->tol_keff; A.tol_flux = o->tol_flux; A.cg_tol = cg_tol; A.cg_max = cg_max; A.max_outer = o->max_outer;
     A.ca1 = ca[1];
     for (int i = 2; i < 15; ++i) { A.a3[i] = (4. / sigma) * ca[i]; A.cb[i] = cbv[i]; }
-    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer)); T->hist_cap = o->max_outer; }
+    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer + 8)); T->hist_cap = o->max_outer; }
+#ifdef NF_STAMPS
+    (void)hipMemsetAsync(T->d_hist + 3 * (size_t)o->max_outer, 0, 8 * sizeof(double), st);
+#endif
     if (T->hist_cg_cap < o->max_outer * ng) { NFCHK(dalloc(&T->d_hist_cg, (size_t)o->max_outer * ng)); T->hist_cg_cap = o->max_outer * ng; }
     if (!T->d_rout) NFCHK(dalloc(&T->d_rout, 1));
     A.hist = T->d_hist; A.hist_cg = T->d_hist_cg; A.out = T->d_rout;
@@ -1973,9 +1976,30 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     // LDS plan: 160 KiB per workgroup; behind the scratch of the direction passes the CG vectors and this group's factors, in
     // priority order, as far as they fit (ResidentArgs::lds_mask)
     A.Cd0 = S->d_Cd; A.lds_mask = 0;
+    // RT0-P0: the line-per-lane variant when everything its sweeps touch fits in LDS (p, the contribution of every direction, the
+    // factors and first pivots); r, x_sol and the C diagonal follow as far as there is room
+    const long cap = 160 * 1024 / 8 - 32;
+    bool serial = false;
+    if (S->nb == 0 && T->opt_resident_serial && T->opt_resident_lds) {
+        const long N2 = (S->N + 1) & ~1L;
+        const int pitch = S->N <= 1536 ? 1536 : 2000;
+        long need = 64 + 16 + 4 * N2 + 3L * S->dim * pitch;
+        int slot = 0;
+        for (int d = 0; d < S->dim; ++d) { need += (S->nlines[d] + 1) & ~1L; A.slot0[d] = slot; slot += (int)((S->nlines[d] + 63) / 64) * 64; }
+        for (int d = S->dim; d < 4; ++d) A.slot0[d] = slot;
+        if (S->N <= pitch && need <= cap) {
+            serial = true;
+            const size_t lds = (size_t)need * sizeof(double);
+#define NF_RES_SERIAL(P) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<false, 0, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_resident_keff<false, 0, P>), dim3(1), dim3(B), lds, st, A); } while (0)
+            if (pitch == 1536) NF_RES_SERIAL(1536); else NF_RES_SERIAL(2000);
+#undef NF_RES_SERIAL
+        }
+    }
+    T->last_resident_serial = serial ? 1 : 0;
+    if (!serial) {
     long used = 5 * B + 64 + 16;
     if (T->opt_resident_lds) {
-        const long cap = 160 * 1024 / 8 - 32;
         const long NP2 = (S->nphi + 1) & ~1L, N2 = (S->N + 1) & ~1L;
         const int bits[11] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10 };
         for (int b : bits) {
@@ -1993,6 +2017,7 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     else if (S->nb == 1) { if (vec) NF_RES(true, 1); else NF_RES(false, 1); }
     else { if (vec) NF_RES(true, 2); else NF_RES(false, 2); }
 #undef NF_RES
+    }
     HIPCHK(hipGetLastError());
     ResidentOut ro;
     HIPCHK(hipMemcpyAsync(&ro, T->d_rout, sizeof ro, hipMemcpyDeviceToHost, st));
@@ -2008,6 +2033,11 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     }
     T->last_outer = n; T->last_cg_total = ro.cg_total;
     if (ro.status == 2) return fail(NF_ERR_NUMERIC, "power iteration diverged (outer %d: k=%g dphi=%g)", n - 1, T->hist_k[n - 1], T->hist_dphi[n - 1]);
+#ifdef NF_STAMPS
+    { long long acc[5]; (void)hipMemcpy(acc, T->d_hist + 3 * (size_t)o->max_outer, sizeof acc, hipMemcpyDeviceToHost);
+      if (acc[4] > 0) fprintf(stderr, "[resident stamps] %lld CG iterations: x pass %.0f, y/z passes %.0f, p.q reduction %.0f, r update + |r|^2 reduction %.0f cycles per iteration\n",
+                              acc[4], (double)acc[0] / acc[4], (double)acc[1] / acc[4], (double)acc[2] / acc[4], (double)acc[3] / acc[4]); }
+#endif
     *keff_out = ro.keff;
     return NF_OK;
 }
@@ -2422,6 +2452,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "cg_lean_max_cells")) T->lean_max_cells = value;
     else if (!strcmp(key, "resident")) T->opt_resident = value != 0;
     else if (!strcmp(key, "resident_lds")) T->opt_resident_lds = value != 0;
+    else if (!strcmp(key, "resident_serial")) T->opt_resident_serial = value != 0;
     else if (!strcmp(key, "resident_max_dofs")) T->resident_max_dofs = value;
     else if (!strcmp(key, "direct_max_dofs")) T->direct_max_dofs = std::max(0L, std::min(8192L, value));
     else if (!strcmp(key, "cg_fuse3")) T->opt_fuse3 = value != 0;

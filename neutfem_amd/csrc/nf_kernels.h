@@ -55,6 +55,49 @@ __device__ __forceinline__ double wave_sum(double v)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// ---- cross-lane moves and scans of affine maps z -> A z + B with data-parallel primitives -------------------------------------
+// lanes without a valid source (row / wavefront edge, or outside ROW_MASK) receive `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v, double old)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_above(double v) { return dpp_get<0x130, 0xF>(v, v); }   // wave_shl:1 = value of lane + 1
+__device__ __forceinline__ double lane_below(double v) { return dpp_get<0x138, 0xF>(v, v); }   // wave_shr:1 = value of lane - 1
+// Inclusive scan over groups of LPL consecutive lanes (LPL = 1, 2, 4 ... 64): afterwards lane li holds f_li o ... o f_0 of its group.
+// row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast 15 / 31 hand the totals of the lower rows upwards; no LDS crossbar.
+#define NF_SCAN_STEP(CTRL, D) if (LPL > D) { double Ap = dpp_get<CTRL, 0xF>(A, 1.0), Bp = dpp_get<CTRL, 0xF>(B, 0.0); \
+                                             if (pos < D) { Ap = 1.0; Bp = 0.0; } B = A * Bp + B; A = A * Ap; }
+__device__ __forceinline__ void scan_maps_up(double &A, double &B, int LPL, int lane)
+{
+    const int pos = lane & ((LPL < 16 ? LPL : 16) - 1);
+    NF_SCAN_STEP(0x111, 1) NF_SCAN_STEP(0x112, 2) NF_SCAN_STEP(0x114, 4) NF_SCAN_STEP(0x118, 8)
+    if (LPL > 16) { const double Ap = dpp_get<0x142, 0xA>(A, 1.0), Bp = dpp_get<0x142, 0xA>(B, 0.0); B = A * Bp + B; A = A * Ap; }
+    if (LPL > 32) { const double Ap = dpp_get<0x143, 0xC>(A, 1.0), Bp = dpp_get<0x143, 0xC>(B, 0.0); B = A * Bp + B; A = A * Ap; }
+}
+// The mirror image: lane li holds f_li o f_{li+1} o ... o f_{LPL-1}.  row_shl inside the rows; the totals of the higher rows come down
+// through at most two crossbar reads (there is no downward row broadcast).
+#define NF_SCAN_STEP_DN(CTRL, D) if (LPL > D) { double Ap = dpp_get<CTRL, 0xF>(A, 1.0), Bp = dpp_get<CTRL, 0xF>(B, 0.0); \
+                                                if (pos + D >= W) { Ap = 1.0; Bp = 0.0; } B = A * Bp + B; A = A * Ap; }
+__device__ __forceinline__ void scan_maps_down(double &A, double &B, int LPL, int lane)
+{
+    const int W = LPL < 16 ? LPL : 16, pos = lane & (W - 1);
+    NF_SCAN_STEP_DN(0x101, 1) NF_SCAN_STEP_DN(0x102, 2) NF_SCAN_STEP_DN(0x104, 4) NF_SCAN_STEP_DN(0x108, 8)
+    if (LPL > 16) {                                              // even rows take the suffix total of the row above (its first lane)
+        const int src = (lane & ~31) + 16;
+        double Ap = __shfl(A, src, 64), Bp = __shfl(B, src, 64);
+        if (lane & 16) { Ap = 1.0; Bp = 0.0; }
+        B = A * Bp + B; A = A * Ap;
+    }
+    if (LPL > 32) {                                              // the lower half takes the total of the upper half (lane 32)
+        double Ap = __shfl(A, 32, 64), Bp = __shfl(B, 32, 64);
+        if (lane >= 32) { Ap = 1.0; Bp = 0.0; }
+        B = A * Bp + B; A = A * Ap;
+    }
+}
+
 // fixed-order block sum; result valid in thread 0.  sred: >= blockDim/64 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *sred)
 {
@@ -505,7 +548,10 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
 struct CgFuse { double *p; const double *r; double *xsol; double *pout; };
 
 // One wave-task of the x pass: 64/LPL lines, lane = (line of the task, position in the line).  Returns the lane's share of x.y.
-template <int K, int NCH, bool VEC, int NB, class Mid = NoMid>
+// DPPS: cross-lane traffic of the scans through data-parallel primitives (VALU) instead of ds_bpermute (LDS crossbar).  That halves
+// the latency of a lone wave-task (resident kernel: 14.2 k -> 10.9 k cycles per x pass) but costs VALU issue slots: with many waves
+// per SIMD the crossbar version is faster (fused-direction launch at 128^3: 76.8 vs 82.9 us per CG iteration on the same box).
+template <int K, int NCH, bool VEC, int NB, class Mid = NoMid, bool DPPS = false>
 __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2, int first,
                                                long task, int lane, bool active, bool fuse, double f_alpha, double f_beta, const CgFuse &fz, Mid mid = Mid())
@@ -580,7 +626,7 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
     double carry = z0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        double xn = __shfl_down(xL[ch][0], 1, LPL);
+        double xn = DPPS ? lane_above(xL[ch][0]) : __shfl_down(xL[ch][0], 1, LPL);
         double xc = 0.0;
         if (ch + 1 < NCH) xc = __shfl(xL[ch + 1 < NCH ? ch + 1 : ch][0], 0, LPL);
         if (li == LPL - 1) xn = xc;
@@ -590,21 +636,22 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
         double A = 1.0, B = 0.0;
 #pragma unroll
         for (int j = 0; j < K; ++j) { B = t[j] - Ls[ch][j] * B; A = -Ls[ch][j] * A; }
-        for (int d = 1; d < LPL; d <<= 1) {
+        if (DPPS) scan_maps_up(A, B, LPL, lane);
+        else for (int d = 1; d < LPL; d <<= 1) {
             const double Ap = __shfl_up(A, d, LPL), Bp = __shfl_up(B, d, LPL);
             if (li >= d) { B = A * Bp + B; A = A * Ap; }
         }
-        const double Ae = __shfl_up(A, 1, LPL), Be = __shfl_up(B, 1, LPL);
+        const double Ae = DPPS ? lane_below(A) : __shfl_up(A, 1, LPL), Be = DPPS ? lane_below(B) : __shfl_up(B, 1, LPL);
         double z = li == 0 ? carry : Ae * carry + Be;
 #pragma unroll
         for (int j = 0; j < K; ++j) { z = t[j] - Ls[ch][j] * z; w[ch][j] = z * Rs[ch][j]; }
-        carry = __shfl(z, LPL - 1, LPL);
+        if (ch + 1 < NCH) carry = __shfl(z, LPL - 1, LPL);
     }
     // ---- backward sweep over chunks
     double ucarry = 0.0, dot = 0.0;
 #pragma unroll
     for (int ch = NCH - 1; ch >= 0; --ch) {
-        double Ln = __shfl_down(Ls[ch][0], 1, LPL);
+        double Ln = DPPS ? lane_above(Ls[ch][0]) : __shfl_down(Ls[ch][0], 1, LPL);
         double Lc = 0.0;
         if (ch + 1 < NCH) Lc = __shfl(Ls[ch + 1 < NCH ? ch + 1 : ch][0], 0, LPL);
         if (li == LPL - 1) Ln = Lc;
@@ -614,17 +661,18 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
         double A = 1.0, B = 0.0;
 #pragma unroll
         for (int j = K - 1; j >= 0; --j) { B = w[ch][j] - Lup[j] * B; A = -Lup[j] * A; }
-        for (int d = 1; d < LPL; d <<= 1) {
+        if (DPPS) scan_maps_down(A, B, LPL, lane);
+        else for (int d = 1; d < LPL; d <<= 1) {
             const double Ap = __shfl_down(A, d, LPL), Bp = __shfl_down(B, d, LPL);
             if (li + d < LPL) { B = A * Bp + B; A = A * Ap; }
         }
-        const double Ae = __shfl_down(A, 1, LPL), Be = __shfl_down(B, 1, LPL);
+        const double Ae = DPPS ? lane_above(A) : __shfl_down(A, 1, LPL), Be = DPPS ? lane_above(B) : __shfl_down(B, 1, LPL);
         double u = li == LPL - 1 ? ucarry : Ae * ucarry + Be;
         double uv[K];
 #pragma unroll
         for (int j = K - 1; j >= 0; --j) { u = w[ch][j] - Lup[j] * u; uv[j] = u; }
-        ucarry = __shfl(uv[0], 0, LPL);
-        double ulo = __shfl_up(uv[K - 1], 1, LPL);
+        if (ch > 0) ucarry = __shfl(uv[0], 0, LPL);
+        double ulo = DPPS ? lane_below(uv[K - 1]) : __shfl_up(uv[K - 1], 1, LPL);
         double wprev = 0.0;
         if (ch > 0) wprev = __shfl(w[ch > 0 ? ch - 1 : 0][K - 1], LPL - 1, LPL);
         if (li == 0) ulo = (ch == 0 ? z0 * d0 : wprev) - Ls[ch][0] * uv[0];
@@ -1488,6 +1536,9 @@ struct ResidentArgs {
     // LDS residency (host plan, greedy by priority): bit 0 p, 1 q, 2 r, 3 x_sol, 4+2d L[d], 5+2d DR[d], 10 C diagonal.  One CU
     // moves ~10 B/cycle to and from L2 but 128 B/cycle to and from LDS, and a barrier no longer waits for global store acks.
     const double *Cd0; int lds_mask;
+    // RT0-P0 "line per lane" variant (k_resident_keff<.., 0, true>): lane slots of the directions (each direction starts on a wavefront
+    // boundary), and two spare vectors for the y / z contributions should they not fit in LDS (they always do under the host's plan)
+    int slot0[4];
 };
 __device__ __forceinline__ double block_total(double v, double *sred)     // fixed-order sum over the block, result in every thread
 {
@@ -1497,6 +1548,72 @@ __device__ __forceinline__ double block_total(double v, double *sred)     // fix
     v = sred[0];
     __syncthreads();
     return v;
+}
+// One barrier instead of four: every wavefront leaves its partial in the buffer of the given parity and every thread adds the (at most 8)
+// partials in the same fixed order.  Two reductions of the same parity must be separated by a barrier (the CG loop alternates).
+__device__ __forceinline__ double block_total_1b(double v, double *sred, int parity)
+{
+    v = wave_sum(v);
+    double *b = sred + parity * 8;
+    const int nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) b[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += b[w];
+    return s;
+}
+// RT0-P0 on a mesh that lives in LDS: one lane per line, both sweeps serial along the line -- no scans, no barriers.  For lines of a few
+// dozen cells the dependent chain of n multiply-adds per sweep is several times shorter than the instruction stream of the segmented
+// scans (in-kernel stamps, IAEA-2D 38 x 38: 10.9 k + 6.2 k cycles for the x and y passes of the scan kernels).
+//   forward  z_{c+1} = (x_c - x_{c+1}) - L_c z_c, z_0 = -x_0, w_f = z_f / d_f ; backward u_f = w_f - L_f u_{f+1} ; out_c = Ta (u_{c+1} - u_c)
+// blk: the direction's block of three arrays at a compile-time pitch -- L, 1/d, out -- so that one address register serves all three
+// (LDS instructions carry a 16-bit byte offset).  The n - 1 cells that have an upper neighbour go in unpredicated pieces of 8 / 4 / 2 / 1
+// cells (a predicated or clamped load costs more instructions than the arithmetic), the last cell on its own.
+typedef __attribute__((address_space(3))) double lds_f64;      // explicit LDS pointers: ds_read / ds_write with 32-bit addresses, not flat accesses
+template <int CH, int PITCH>
+__device__ __forceinline__ void serial_fwd(const lds_f64 *&xp, lds_f64 *&bp, int sl, double &z, double &xc)
+{
+    double xv[CH + 1], Lv[CH], Rv[CH];
+    xv[0] = xc;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { Lv[i] = bp[i * sl]; Rv[i] = bp[i * sl + PITCH]; xv[i + 1] = xp[(i + 1) * sl]; }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { z = (xv[i] - xv[i + 1]) - Lv[i] * z; bp[i * sl + 2 * PITCH] = z * Rv[i]; }
+    xc = xv[CH]; xp += CH * sl; bp += CH * sl;
+}
+template <int CH, int PITCH>
+__device__ __forceinline__ void serial_bwd(lds_f64 *&bp, int sl, double Ta, double &u2, double &Ln)
+{
+    double wv[CH], Lv[CH];
+    bp -= CH * sl;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { wv[i] = bp[i * sl + 2 * PITCH]; Lv[i] = bp[i * sl]; }
+#pragma unroll
+    for (int i = CH - 1; i >= 0; --i) {
+        const double u1 = wv[i] - Ln * u2;                       // u_{c+1}
+        bp[(i + 1) * sl + 2 * PITCH] = Ta * (u2 - u1);           // cell c + 1
+        u2 = u1; Ln = Lv[i];
+    }
+}
+template <int PITCH>
+__device__ __forceinline__ void serial_line_rt0(const lds_f64 *x, lds_f64 *blk, double d0, double Ta, int n, int base, int sl)
+{
+    const lds_f64 *xp = x + base; lds_f64 *bp = blk + base;
+    double xc = xp[0], z = -xc;
+    const double w0 = z * d0;
+    const int m = n - 1;
+    for (int k = 0; k < (m >> 3); ++k) serial_fwd<8, PITCH>(xp, bp, sl, z, xc);
+    if (m & 4) serial_fwd<4, PITCH>(xp, bp, sl, z, xc);
+    if (m & 2) serial_fwd<2, PITCH>(xp, bp, sl, z, xc);
+    if (m & 1) serial_fwd<1, PITCH>(xp, bp, sl, z, xc);
+    z = xc - bp[0] * z;                                          // the last cell: nothing above it
+    double u2 = z * bp[PITCH], Ln = bp[0];                       // u_n = w_n (L_n = 0)
+    if (m & 1) serial_bwd<1, PITCH>(bp, sl, Ta, u2, Ln);
+    if (m & 2) serial_bwd<2, PITCH>(bp, sl, Ta, u2, Ln);
+    if (m & 4) serial_bwd<4, PITCH>(bp, sl, Ta, u2, Ln);
+    for (int k = 0; k < (m >> 3); ++k) serial_bwd<8, PITCH>(bp, sl, Ta, u2, Ln);
+    const double u0 = w0 - Ln * u2;
+    bp[2 * PITCH] = Ta * (u2 - u0);
 }
 // all tiles of one y / z pass, nconc = blockDim / (TX NSEG) of them side by side; every thread runs every round (barriers inside)
 template <int SEG, int DIR, int NB>
@@ -1521,17 +1638,20 @@ __device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, 
     }
     return dot;
 }
-template <bool VEC, int NB>
+template <bool VEC, int NB, int PITCH = 0>                        // PITCH > 0: the line-per-lane variant (RT0-P0, everything in LDS)
 __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
 {
+    constexpr bool SERIAL = PITCH > 0;
+    static_assert(!SERIAL || NB == 0, "the line-per-lane variant is RT0-P0 only");
     constexpr int SEG = NB > 0 ? 4 : 8;
     extern __shared__ double sm[];
-    double *sred = sm + 5 * (int)blockDim.x + 64;
+    const int scr = SERIAL ? 0 : 5 * (int)blockDim.x;             // scratch of the tiled passes
+    double *sred = sm + scr + 64;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
     const int ng = A.ng; const long N = A.N, NP = A.nphi, NT = NP * ng;
     SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
     // vectors and factors that fit are kept in LDS behind the scratch area (ResidentArgs::lds_mask); the rest stays in global memory
-    double *lds = sm + 5 * (int)blockDim.x + 64 + 16;
+    double *lds = sm + scr + 64 + 16;
     long lo = 0;
     auto carve = [&](int bit, long n) -> double * { if (!((A.lds_mask >> bit) & 1)) return nullptr; double *q_ = lds + lo; lo += (n + 1) & ~1L; return q_; };
     double *vp = carve(0, NP), *vq = carve(1, NP), *vr = carve(2, NP), *vx = carve(3, NP);
@@ -1539,6 +1659,15 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
 #pragma unroll
     for (int d = 0; d < 3; ++d) { fL[d] = carve(4 + 2 * d, N); fR[d] = carve(5 + 2 * d, N); }
     double *fC = carve(10, NP);
+    // line-per-lane variant, all in LDS: p, r, x_sol, the C diagonal, then per direction a block {L, 1/d, contribution} at pitch PITCH
+    // and the first pivots of its lines
+    double *sblk[3] = { nullptr, nullptr, nullptr }, *sD0[3] = { nullptr, nullptr, nullptr };
+    if (SERIAL) {
+        const long N2 = (N + 1) & ~1L;
+        vp = lds; vr = lds + N2; vx = lds + 2 * N2; fC = lds + 3 * N2; lo = 4 * N2;
+        for (int d = 0; d < A.dim; ++d) { sblk[d] = lds + lo; lo += 3 * PITCH; }
+        for (int d = 0; d < A.dim; ++d) { sD0[d] = lds + lo; lo += (A.nlines[d] + 1) & ~1L; }
+    }
     double *const wp = vp ? vp : A.p, *const wq = vq ? vq : A.q, *const wr = vr ? vr : A.r;
     double keff = A.keff0;
     int cheb_it = 0, n_outer = 0, status = 0, cg_total = 0;
@@ -1563,6 +1692,10 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                 if (fR[d]) for (long i = tid; i < N; i += nt) fR[d][i] = A.DR[d][g * N + i];
             }
             if (fC) for (long i = tid; i < NP; i += nt) fC[i] = A.Cd0[g * NP + i];
+            if (SERIAL) for (int d = 0; d < A.dim; ++d) {
+                for (long i = tid; i < N; i += nt) { sblk[d][i] = A.L[d][g * N + i]; sblk[d][PITCH + i] = A.DR[d][g * N + i]; }
+                for (long i = tid; i < A.nlines[d]; i += nt) sD0[d][i] = A.D0[d][g * A.nlines[d] + i];
+            }
             // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
             s = 0.0;
             for (long i = tid; i < NP; i += nt) {
@@ -1592,9 +1725,73 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                 }
                 dL[d] = fL[d] ? fL[d] : A.L[d] + g * N; dR[d] = fR[d] ? fR[d] : A.DR[d] + g * N;
             }
+            if constexpr (SERIAL) {
+                const int nx = A.G.nx, nxy = A.G.nx * A.G.ny, n_ = (int)N;
+                lds_f64 *const lp = (lds_f64 *)vp, *const lr = (lds_f64 *)vr, *const lx = (lds_f64 *)vx, *const lC = (lds_f64 *)fC;
+                lds_f64 *const lb0 = (lds_f64 *)sblk[0], *const lb1 = (lds_f64 *)sblk[1], *const lb2 = (lds_f64 *)sblk[2];
+                const lds_f64 *const lD0 = (const lds_f64 *)sD0[0], *const lD1 = (const lds_f64 *)sD0[1], *const lD2 = (const lds_f64 *)sD0[2];
+                while (its < A.cg_max) {
+#ifdef NF_STAMPS
+                    long long ts0 = (long long)__builtin_readcyclecounter();
+#endif
+                    // ---- every line of every direction at once, one lane each: X p, Y p, Z p into the directions' blocks
+                    for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
+                        const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
+                        const int l = sl_ - A.slot0[d];
+                        if (l < (int)A.nlines[d]) {
+                            if (d == 0) serial_line_rt0<PITCH>(lp, lb0, lD0[l], mad[0].Ta, nx, l * nx, 1);
+                            else if (d == 1) serial_line_rt0<PITCH>(lp, lb1, lD1[l], mad[1].Ta, A.G.ny, (l / nx) * nxy + l % nx, nx);
+                            else serial_line_rt0<PITCH>(lp, lb2, lD2[l], mad[2].Ta, A.G.nz, l, nxy);
+                        }
+                    }
+                    __syncthreads();
+#ifdef NF_STAMPS
+                    long long ts1 = (long long)__builtin_readcyclecounter();
+#endif
+                    // ---- own cells (the same ones in every loop below: no barrier between them): q = C p + X p + Y p + Z p, p.q
+                    lds_f64 *const vq_ = lb0 + 2 * PITCH;
+                    double dot = 0.0;
+                    for (int i = tid; i < n_; i += nt) {
+                        const double pv = lp[i];
+                        double qv = lC[i] * pv + vq_[i];
+                        if (A.dim >= 2) qv += lb1[2 * PITCH + i];
+                        if (A.dim == 3) qv += lb2[2 * PITCH + i];
+                        vq_[i] = qv; dot += pv * qv;
+                    }
+#ifdef NF_STAMPS
+                    long long ts2 = (long long)__builtin_readcyclecounter();
+#endif
+                    const double pq = block_total_1b(dot, sred, 0);   // src/solvers.cpp:602-606
+#ifdef NF_STAMPS
+                    long long ts3 = (long long)__builtin_readcyclecounter();
+#endif
+                    if (fabs(pq) < 1e-30) break;
+                    alpha = rr / pq;
+                    s = 0.0;
+                    for (int i = tid; i < n_; i += nt) { const double rn = lr[i] - alpha * vq_[i]; lr[i] = rn; s += rn * rn; }
+                    const double rr_new = block_total_1b(s, sred, 1);   // :613-631
+                    ++its;
+                    const bool conv = rr_new < tol_sq;
+                    beta = rr_new / rr; rr = rr_new;
+                    for (int i = tid; i < n_; i += nt) {          // :609, :630
+                        const double pv = lp[i];
+                        lx[i] = fma(alpha, pv, lx[i]);
+                        if (!conv) lp[i] = fma(beta, pv, lr[i]);
+                    }
+                    __syncthreads();
+#ifdef NF_STAMPS
+                    if (tid == 0 && A.hist) { long long ts4 = (long long)__builtin_readcyclecounter(); long long *acc = (long long *)(A.hist + 3 * A.max_outer);
+                                              acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1; }
+#endif
+                    if (conv) break;
+                }
+            } else
             while (its < A.cg_max) {
                 const bool fuse = its > 0;
                 double dot = 0.0;
+#ifdef NF_STAMPS
+                long long ts0 = (long long)__builtin_readcyclecounter();
+#endif
                 // ---- x lines: q = C p + X p, carrying the deferred x_sol += alpha p, p = r + beta p of the previous iteration
                 const int ntask = A.ntask_x * A.nmodes;
                 for (int gt0 = 0; gt0 < ntask; gt0 += nw) {
@@ -1602,21 +1799,34 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                     const bool active = gt < ntask;
                     const int mode = active ? gt / A.ntask_x : 0;
                     const ModeArgs ma = select_mode(mad[0], A.mt[0], mode, NB + 1);
-                    const double dx = schur_x_task<2, 1, VEC, NB>(ma, A.G, dL[0], dR[0], A.D0[0] + g * A.nlines[0], A.G.nx, A.G.ny,
+                    const double dx = schur_x_task<2, 1, VEC, NB, NoMid, true>(ma, A.G, dL[0], dR[0], A.D0[0] + g * A.nlines[0], A.G.nx, A.G.ny,
                                                                   A.nlines[0], A.lpl_log2, 1, gt % A.ntask_x, tid & 63, active, fuse, alpha, beta, fz);
                     if (A.dim == 1) dot += dx;
                 }
                 __syncthreads();
+#ifdef NF_STAMPS
+                long long ts1 = (long long)__builtin_readcyclecounter();
+#endif
                 // ---- y, then z lines: accumulate into q; the last direction also gives p.q
                 if (A.dim >= 2) { const double ds = resident_s_pass<SEG, 1, NB>(A, 0, mad[1], dL[1], dR[1], g, sm, sa0, fz); if (A.dim == 2) dot += ds; }
                 if (A.dim == 3) dot += resident_s_pass<SEG, 2, NB>(A, 1, mad[2], dL[2], dR[2], g, sm, sa0, fz);
+#ifdef NF_STAMPS
+                long long ts2 = (long long)__builtin_readcyclecounter();
+#endif
                 const double pq = block_total(dot, sred);       // src/solvers.cpp:602-606
+#ifdef NF_STAMPS
+                long long ts3 = (long long)__builtin_readcyclecounter();
+#endif
                 pend = 0;
                 if (fabs(pq) < 1e-30) break;
                 alpha = rr / pq;
                 s = 0.0;
                 for (long i = tid; i < NP; i += nt) { const double rn = wr[i] - alpha * wq[i]; wr[i] = rn; s += rn * rn; }
                 const double rr_new = block_total(s, sred);     // :613-631
+#ifdef NF_STAMPS
+                if (tid == 0 && A.hist) { long long ts4 = (long long)__builtin_readcyclecounter(); long long *acc = (long long *)(A.hist + 3 * A.max_outer);
+                                          acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1; }
+#endif
                 ++its; pend = 1;
                 if (rr_new < tol_sq) { rr = rr_new; break; }
                 beta = rr_new / rr; rr = rr_new;

@@ -9,7 +9,8 @@ from helpers import TEST_TOL, degenerate_inputs, load_inputs, make_hip, make_ora
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2)]
+PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
+         ("resident-scans", dict(resident=1, resident_max_dofs=100000, resident_serial=0), 2)]   # RT0-P0 small enough for LDS: "resident" is the line-per-lane variant
 
 
 def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
@@ -36,7 +37,7 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
         assert rel_l2(r["J"].ravel(), o.J_dofs().ravel()) < 1e-7, name
-    for name in ("fuse3", "resident"):
+    for name in ("fuse3", "resident", "resident-scans"):
         assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
         assert rel_l2(res[name]["phi"], res["classic"]["phi"]) < 1e-9
 
@@ -63,7 +64,7 @@ def test_resident_path_limits_and_warm_start():
     inp = load_inputs("iaea2d")
     o = make_oracle(inp); s = make_hip(inp)
     o.set_tol(*TEST_TOL); s.set_tol(*TEST_TOL)
-    k1, n1 = s.solve_keff(); assert s.info("last_path") == 2
+    k1, n1 = s.solve_keff(); assert s.info("last_path") == 2 and s.info("last_resident_serial") == 1
     ko1 = o.SolveKeff(); assert abs(k1 - ko1) / ko1 < 1e-9 and n1 == o.info("last_outer")
     k2, n2 = s.solve_keff(); ko2 = o.SolveKeff()                    # warm start from the last k and flux (src/NeutFEM.cpp:1662)
     assert abs(k2 - ko2) / ko2 < 1e-9 and n2 == o.info("last_outer") and n2 < n1
@@ -73,6 +74,8 @@ def test_resident_path_limits_and_warm_start():
     s.reset_flux(); s.solve_keff(False, (), True); assert s.info("last_path") == 1      # diagonal path keeps its own device loop
     s.set_tol(0.0, 1e-4, 1e-4, 3, 1000); s.reset_flux()
     k4, n4 = s.solve_keff(); assert n4 == 3 and s.info("last_path") == 2 and len(s.history()["k"]) == 3
+    s.set_option("resident_serial", 0); s.set_tol(*TEST_TOL); s.reset_flux()
+    k5, n5 = s.solve_keff(); assert s.info("last_resident_serial") == 0 and n5 == n1 and abs(k5 - k1) / k1 < 1e-9
     s.close()
 
 
