@@ -174,8 +174,9 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   at most "cg_fuse3_max_cells" cells (default 4 Mi);
  *   "resident" (default 1) runs the whole SolveKeff of an undivided mesh with at most "resident_max_dofs" flux DOFs per group (default
  *   2500) in one workgroup and one launch; "resident_lds" (default 1) keeps its CG vectors and factors in LDS as far as they fit;
- *   "resident_serial" (default 1): RT0-P0 meshes whose lines, factors and directions' contributions all fit in LDS run one lane per
- *   line with serial sweeps instead of the segmented scans (nf_info "last_resident_serial");
+ *   "resident_serial" (default 1): meshes whose moments, factors and directions' contributions all fit in LDS run one lane per
+ *   (direction, transverse mode, line) with serial sweeps instead of the segmented scans (nf_info "last_resident_serial"), up to
+ *   "resident_serial_max_dofs" flux DOFs per group (default 5120, the structural limit; "resident_max_dofs" lowers it too);
  *   "direct_max_dofs" (default 2048, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
  *   CG to 1e-14 stands in (nf_info "direct_standin_unconverged" counts group solves that did not get there);
  *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);

@@ -122,7 +122,7 @@ struct nf_team {
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
     int opt_fuse3 = 1; long fuse3_max_cells = 4L << 20;   // fused-direction CG (two launches per iteration) up to this many cells
-    int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, last_resident_serial = 0; long resident_max_dofs = 2500;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
+    int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
     long direct_max_dofs = 2048;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group
@@ -1558,7 +1558,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
         CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
-        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->resident_max_dofs = T->resident_max_dofs;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
     double kc = 1.0; int nout = 0;
@@ -1946,13 +1946,25 @@ static bool resident_plan(const nf_solver *S, ResidentArgs *A)
     A->lpl_log2 = lpl_log2; A->ntask_x = (int)((S->nlines[0] + LPW - 1) / LPW);
     return true;
 }
+// does the line-per-lane variant of the resident kernel take this mesh?  (the same arithmetic as the plan inside solve_keff_resident)
+static bool resident_serial_fits(const nf_team *T, const nf_solver *S)
+{
+    if (!T->opt_resident_serial || !T->opt_resident_lds) return false;
+    const long cap = 160 * 1024 / 8 - 32;
+    const long Np = (long)(S->nx | 1) * S->ny * S->nz;
+    long lines = 0; for (int d = 0; d < S->dim; ++d) lines += (S->nlines[d] + 1) & ~1L;
+    if (S->nb == 0) { const long pitch = Np <= 1536 ? 1536 : 2560; return Np <= pitch && 64 + 16 + (1 + 3L * S->dim) * pitch + lines <= cap; }
+    const long PC = (Np + 63) & ~63L, NPp = PC * S->nloc;
+    return NPp <= 5120 && n_modes(S) <= 9 && S->nloc <= 27 && 64 + 16 + 176 + (1 + S->dim) * NPp + 2L * S->dim * PC + lines <= cap;
+}
 static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, const double *ca, const double *cbv, double sigma,
                                double cg_tol, int cg_max, double *keff_out)
 {
     nf_solver *S = T->slabs[0];
     const int ng = S->ng; hipStream_t st = T->stream;
     ResidentArgs A; memset(&A, 0, sizeof A);
-    if (!resident_plan(S, &A)) return fail(NF_ERR_STATE, "resident solve: mesh not eligible");
+    const bool planned = resident_plan(S, &A);
+    if (!planned && !resident_serial_fits(T, S)) return fail(NF_ERR_STATE, "resident solve: mesh not eligible");
     A.G = make_geom(S); A.ng = ng; A.dim = S->dim; A.nmodes = n_modes(S); A.N = S->N; A.nphi = S->nphi;
     for (int d = 0; d < 3; ++d) {
         const int dd = d < S->dim ? d : 0;
@@ -1980,23 +1992,51 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     // factors and first pivots); r, x_sol and the C diagonal follow as far as there is room
     const long cap = 160 * 1024 / 8 - 32;
     bool serial = false;
-    if (S->nb == 0 && T->opt_resident_serial && T->opt_resident_lds) {
-        const long N2 = (S->N + 1) & ~1L;
-        const int pitch = S->N <= 1536 ? 1536 : 2000;
-        long need = 64 + 16 + 4 * N2 + 3L * S->dim * pitch;
+    if (S->nb == 0 && T->opt_resident_serial && T->opt_resident_lds && S->nphi <= T->resident_serial_max_dofs) {
+        const long Np = (long)(S->nx | 1) * S->ny * S->nz;     // rows padded to an odd length (bank-conflict-free x lines)
+        const int pitch = Np <= 1536 ? 1536 : 2560;              // multiples of 512 (cells per thread) and of 64 (ds_read2st64)
+        long need = 64 + 16 + (1 + 3L * S->dim) * pitch;
         int slot = 0;
         for (int d = 0; d < S->dim; ++d) { need += (S->nlines[d] + 1) & ~1L; A.slot0[d] = slot; slot += (int)((S->nlines[d] + 63) / 64) * 64; }
         for (int d = S->dim; d < 4; ++d) A.slot0[d] = slot;
-        if (S->N <= pitch && need <= cap) {
+        if (Np <= pitch && need <= cap) {
             serial = true;
             const size_t lds = (size_t)need * sizeof(double);
 #define NF_RES_SERIAL(P) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<false, 0, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((k_resident_keff<false, 0, P>), dim3(1), dim3(B), lds, st, A); } while (0)
-            if (pitch == 1536) NF_RES_SERIAL(1536); else NF_RES_SERIAL(2000);
+            if (pitch == 1536) NF_RES_SERIAL(1536); else NF_RES_SERIAL(2560);
 #undef NF_RES_SERIAL
         }
     }
+    // RT_k-P_m with bubble moments: the same idea, DOF = moment * PC + padded cell, one contribution vector per direction
+    if (S->nb > 0 && T->opt_resident_serial && T->opt_resident_lds && S->nphi <= T->resident_serial_max_dofs) {
+        const long Np = (long)(S->nx | 1) * S->ny * S->nz;
+        const long PC = (Np + 63) & ~63L, NPp = PC * S->nloc;
+        const int nm = n_modes(S);
+        long need = 64 + 16 + 176 + (1 + S->dim) * NPp + 2L * S->dim * PC;
+        int slot = 0;
+        for (int d = 0; d < S->dim; ++d) { need += (S->nlines[d] + 1) & ~1L; A.slot0[d] = slot; slot += (int)((S->nlines[d] * nm + 63) / 64) * 64; }
+        for (int d = S->dim; d < 4; ++d) A.slot0[d] = slot;
+        if (NPp <= 5120 && nm <= 9 && S->nloc <= 27 && need <= cap) {
+            serial = true;
+            A.PC = (int)PC;
+            memset(A.mom, 0, sizeof A.mom); memset(A.diagc, 0, sizeof A.diagc);
+            const ModeArgs c = mode_args(S, 0, 0, 0, S->d_p, S->d_q);
+            for (int d = 0; d < S->dim; ++d)
+                for (int m = 0; m < nm; ++m) {
+                    double Ta = 1.0;
+                    for (int i = 0; i <= S->nb; ++i) A.mom[d][m][i] = moment_index(S, d, m, i, &Ta);
+                    for (int l = 0; l < S->nb; ++l) A.diagc[A.mom[d][m][l + 1]][d] = Ta * c.Gc[l] * c.Gc[l] * c.iM[l];
+                }
+            const size_t lds = (size_t)need * sizeof(double);
+#define NF_RES_HI(NBV) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<false, NBV, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_resident_keff<false, NBV, -1>), dim3(1), dim3(B), lds, st, A); } while (0)
+            if (S->nb == 1) NF_RES_HI(1); else NF_RES_HI(2);
+#undef NF_RES_HI
+        }
+    }
     T->last_resident_serial = serial ? 1 : 0;
+    if (!serial && !planned) return fail(NF_ERR_STATE, "resident solve: mesh not eligible");
     if (!serial) {
     long used = 5 * B + 64 + 16;
     if (T->opt_resident_lds) {
@@ -2094,8 +2134,8 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
     T->last_path = 0;
     {
         ResidentArgs probe;
-        if (single && !use_diag && !use_cmfd && !direct && !T->rccl_reduce && T->opt_resident && o->max_outer > 0 && S0->nphi <= T->resident_max_dofs &&
-            resident_plan(S0, &probe)) {
+        if (single && !use_diag && !use_cmfd && !direct && !T->rccl_reduce && T->opt_resident && o->max_outer > 0 &&
+            ((S0->nphi <= T->resident_max_dofs && resident_plan(S0, &probe)) || (S0->nphi <= T->resident_serial_max_dofs && resident_serial_fits(T, S0)))) {
             T->last_path = 2; T->profile = false;
             NFCHK(solve_keff_resident(T, o, keff, ca, cbv, sigma, cg_tol, cg_max, &keff));
             S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = false; S0->jz_valid = false;
@@ -2453,7 +2493,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "resident")) T->opt_resident = value != 0;
     else if (!strcmp(key, "resident_lds")) T->opt_resident_lds = value != 0;
     else if (!strcmp(key, "resident_serial")) T->opt_resident_serial = value != 0;
-    else if (!strcmp(key, "resident_max_dofs")) T->resident_max_dofs = value;
+    else if (!strcmp(key, "resident_max_dofs")) { T->resident_max_dofs = value; T->resident_serial_max_dofs = std::min<long>(value, 5120); }   // one knob caps both variants
+    else if (!strcmp(key, "resident_serial_max_dofs")) T->resident_serial_max_dofs = value;
     else if (!strcmp(key, "direct_max_dofs")) T->direct_max_dofs = std::max(0L, std::min(8192L, value));
     else if (!strcmp(key, "cg_fuse3")) T->opt_fuse3 = value != 0;
     else if (!strcmp(key, "cg_fuse3_max_cells")) T->fuse3_max_cells = value;

@@ -1539,6 +1539,10 @@ struct ResidentArgs {
     // RT0-P0 "line per lane" variant (k_resident_keff<.., 0, true>): lane slots of the directions (each direction starts on a wavefront
     // boundary), and two spare vectors for the y / z contributions should they not fit in LDS (they always do under the host's plan)
     int slot0[4];
+    // the same for RT_k-P_m with bubble moments (k_resident_keff<.., NB > 0, -1>): cell pitch, the moment index of every (direction,
+    // transverse mode, along-index), and per (moment, direction) the factor T_a G_l^2 / M^bb_l of the bubble's diagonal term (0 when
+    // the moment has no bubble in that direction), which is folded into the C diagonal once per group
+    int PC, mom[3][9][3]; double diagc[27][3];
 };
 __device__ __forceinline__ double block_total(double v, double *sred)     // fixed-order sum over the block, result in every thread
 {
@@ -1615,6 +1619,79 @@ __device__ __forceinline__ void serial_line_rt0(const lds_f64 *x, lds_f64 *blk, 
     const double u0 = w0 - Ln * u2;
     bp[2 * PITCH] = Ta * (u2 - u0);
 }
+// The same for RT_k-P_m with NB bubble moments (formulas above ModeArgs).  x / y: moment 0 of the line's transverse mode at the first cell,
+// o1 / o2: offsets of the along-moments 1 and 2; L at the first cell, 1/d at offset oR.  The bubbles' own diagonal term
+// T_a G_l^2 x_{l+1} / (M^bb_l c_e) is not formed here: it sits in the thread-private C diagonal of the cell pass.
+struct HiConst { double eL[2], eR[2], Gc[2]; };
+template <int NB>
+__device__ __forceinline__ void hi_faces(double x0, double x1, double x2, const HiConst &c, double &xL, double &xR)
+{
+    double pl = 0.0, pr = 0.0;
+    if (NB > 0) { const double g = c.Gc[0] * x1; pl += c.eL[0] * g; pr += c.eR[0] * g; }
+    if (NB > 1) { const double g = c.Gc[1] * x2; pl += c.eL[1] * g; pr += c.eR[1] * g; }
+    xL = x0 + pl; xR = x0 - pr;
+}
+template <int CH, int NB>
+__device__ __forceinline__ void hi_fwd(const lds_f64 *&xp, int o1, int o2, const lds_f64 *&Lp, int oR, lds_f64 *&wp, int sl, double &z, double &xRc,
+                                       const HiConst &c)
+{
+    double x0[CH], x1[CH], x2[CH], Lv[CH], Rv[CH];              // xp: the cell above the current one; Lp, wp: the current cell
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        x0[i] = xp[i * sl]; x1[i] = NB > 0 ? xp[i * sl + o1] : 0.0; x2[i] = NB > 1 ? xp[i * sl + o2] : 0.0;
+        Lv[i] = Lp[i * sl]; Rv[i] = Lp[i * sl + oR];
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        double xLn, xRn;
+        hi_faces<NB>(x0[i], x1[i], x2[i], c, xLn, xRn);
+        z = (xRc - xLn) - Lv[i] * z; wp[i * sl] = z * Rv[i]; xRc = xRn;
+    }
+    xp += CH * sl; Lp += CH * sl; wp += CH * sl;
+}
+template <int NB>
+__device__ __forceinline__ void hi_emit(lds_f64 *yp, int o1, int o2, double Ta, double lo, double hi, const HiConst &c)
+{
+    yp[0] = Ta * (hi - lo);
+    if (NB > 0) yp[o1] = -(Ta * c.Gc[0]) * (c.eL[0] * lo + c.eR[0] * hi);
+    if (NB > 1) yp[o2] = -(Ta * c.Gc[1]) * (c.eL[1] * lo + c.eR[1] * hi);
+}
+template <int CH, int NB>
+__device__ __forceinline__ void hi_bwd(const lds_f64 *&Lp, lds_f64 *&yp, int o1, int o2, int sl, double Ta, double &u2, double &Ln, const HiConst &c)
+{
+    double wv[CH], Lv[CH];
+    Lp -= CH * sl; yp -= CH * sl;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { wv[i] = yp[i * sl]; Lv[i] = Lp[i * sl]; }
+#pragma unroll
+    for (int i = CH - 1; i >= 0; --i) {
+        const double u1 = wv[i] - Ln * u2;                       // u_{c+1}: lower face of cell c + 1, u2 its upper face
+        hi_emit<NB>(yp + (i + 1) * sl, o1, o2, Ta, u1, u2, c);
+        u2 = u1; Ln = Lv[i];
+    }
+}
+template <int NB>
+__device__ __forceinline__ void serial_line_hi(const lds_f64 *x, int o1, int o2, const lds_f64 *L, int oR, lds_f64 *y, double d0, double Ta,
+                                               const HiConst &c, int n, int sl)
+{
+    const lds_f64 *xp = x + sl, *Lp = L; lds_f64 *wp = y;
+    double xL0, xRc;
+    hi_faces<NB>(x[0], NB > 0 ? x[o1] : 0.0, NB > 1 ? x[o2] : 0.0, c, xL0, xRc);
+    double z = -xL0;
+    const double w0 = z * d0;
+    const int m = n - 1;
+    for (int k = 0; k < (m >> 2); ++k) hi_fwd<4, NB>(xp, o1, o2, Lp, oR, wp, sl, z, xRc, c);
+    if (m & 2) hi_fwd<2, NB>(xp, o1, o2, Lp, oR, wp, sl, z, xRc, c);
+    if (m & 1) hi_fwd<1, NB>(xp, o1, o2, Lp, oR, wp, sl, z, xRc, c);
+    z = xRc - Lp[0] * z;                                         // the last cell: nothing above it
+    double u2 = z * Lp[oR], Ln = Lp[0];
+    lds_f64 *yp = wp;
+    if (m & 1) hi_bwd<1, NB>(Lp, yp, o1, o2, sl, Ta, u2, Ln, c);
+    if (m & 2) hi_bwd<2, NB>(Lp, yp, o1, o2, sl, Ta, u2, Ln, c);
+    for (int k = 0; k < (m >> 2); ++k) hi_bwd<4, NB>(Lp, yp, o1, o2, sl, Ta, u2, Ln, c);
+    const double u0 = w0 - Ln * u2;
+    hi_emit<NB>(yp, o1, o2, Ta, u0, u2, c);
+}
 // all tiles of one y / z pass, nconc = blockDim / (TX NSEG) of them side by side; every thread runs every round (barriers inside)
 template <int SEG, int DIR, int NB>
 __device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, const ModeArgs &mad, const double *Ld, const double *DRd, int g, double *sm,
@@ -1641,11 +1718,13 @@ __device__ __forceinline__ double resident_s_pass(const ResidentArgs &A, int r, 
 template <bool VEC, int NB, int PITCH = 0>                        // PITCH > 0: the line-per-lane variant (RT0-P0, everything in LDS)
 __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
 {
-    constexpr bool SERIAL = PITCH > 0;
-    static_assert(!SERIAL || NB == 0, "the line-per-lane variant is RT0-P0 only");
+    constexpr bool SERIAL = PITCH > 0;                             // RT0-P0 line-per-lane variant
+    constexpr bool SERH = PITCH < 0;                               // line-per-lane variant with bubble moments
+    static_assert(!SERIAL || NB == 0, "a compile-time pitch is the RT0-P0 variant");
+    static_assert(!SERH || NB > 0, "the run-time pitch variant is for NB > 0");
     constexpr int SEG = NB > 0 ? 4 : 8;
     extern __shared__ double sm[];
-    const int scr = SERIAL ? 0 : 5 * (int)blockDim.x;             // scratch of the tiled passes
+    const int scr = (SERIAL || SERH) ? 0 : 5 * (int)blockDim.x;   // scratch of the tiled passes
     double *sred = sm + scr + 64;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
     const int ng = A.ng; const long N = A.N, NP = A.nphi, NT = NP * ng;
@@ -1659,14 +1738,52 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
 #pragma unroll
     for (int d = 0; d < 3; ++d) { fL[d] = carve(4 + 2 * d, N); fR[d] = carve(5 + 2 * d, N); }
     double *fC = carve(10, NP);
-    // line-per-lane variant, all in LDS: p, r, x_sol, the C diagonal, then per direction a block {L, 1/d, contribution} at pitch PITCH
-    // and the first pivots of its lines
-    double *sblk[3] = { nullptr, nullptr, nullptr }, *sD0[3] = { nullptr, nullptr, nullptr };
+    // Line-per-lane variant.  LDS: p, then per direction a block {L, 1/d, contribution} at pitch PITCH and the first pivots of its lines;
+    // rows padded to an odd length nxp (x lines: lane = line, so the lanes of a wavefront are nxp doubles apart -- odd means no bank
+    // conflicts; an even nx = 38 gave 3-way conflicts on every access and an LDS-bound sweep).  Every thread owns the KC = PITCH / 512
+    // padded cells tid + 512 k for the whole solve and keeps their r, x_sol and C diagonal in registers; cells of the padding and beyond
+    // the mesh hold zeros everywhere, so nothing below is predicated.
+    constexpr int KC = SERIAL ? PITCH / 512 : 1;
+    lds_f64 *lp = nullptr, *lb[3] = { nullptr, nullptr, nullptr }; const lds_f64 *lD[3] = { nullptr, nullptr, nullptr };
+    int gi[KC], nxp = 0;
     if (SERIAL) {
-        const long N2 = (N + 1) & ~1L;
-        vp = lds; vr = lds + N2; vx = lds + 2 * N2; fC = lds + 3 * N2; lo = 4 * N2;
-        for (int d = 0; d < A.dim; ++d) { sblk[d] = lds + lo; lo += 3 * PITCH; }
-        for (int d = 0; d < A.dim; ++d) { sD0[d] = lds + lo; lo += (A.nlines[d] + 1) & ~1L; }
+        nxp = A.G.nx | 1;
+        lp = (lds_f64 *)lds; lo = PITCH;
+        for (int d = 0; d < A.dim; ++d) { lb[d] = (lds_f64 *)(lds + lo); lo += 3 * PITCH; }
+        for (int d = 0; d < A.dim; ++d) { lD[d] = (const lds_f64 *)(lds + lo); lo += (A.nlines[d] + 1) & ~1L; }
+        const int Np = nxp * A.G.ny * A.G.nz;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int ip = tid + k * 512, row = ip / nxp, ix = ip - row * nxp;
+            gi[k] = (ip < Np && ix < A.G.nx) ? row * A.G.nx + ix : -1;
+            lp[ip] = 0.0;
+            for (int d = 0; d < A.dim; ++d) lb[d][2 * PITCH + ip] = 0.0;
+        }
+    }
+    // Higher orders: DOF j = moment * PC + padded cell; p and one contribution vector per direction (nloc PC each), {L, 1/d} per
+    // direction (PC each), first pivots; small tables (moment indices, T_a, diagonal factors) in LDS because a dynamically indexed
+    // kernel argument would move the whole argument struct to scratch.  Every thread owns the DOFs tid + 512 k, k < KD.
+    constexpr int KD = SERH ? 10 : 1;
+    lds_f64 *hp = nullptr, *hc[3] = { nullptr, nullptr, nullptr }, *hL[3] = { nullptr, nullptr, nullptr }, *hD[3] = { nullptr, nullptr, nullptr };
+    lds_f64 *tTa = nullptr, *tDg = nullptr; __attribute__((address_space(3))) int *tMom = nullptr;
+    int gj[KD], hPC = 0, hNPp = 0, hNp = 0;
+    if (SERH) {
+        nxp = A.G.nx | 1; hPC = A.PC; hNp = nxp * A.G.ny * A.G.nz;
+        const int nloc = (int)(NP / N); hNPp = nloc * hPC;
+        tTa = (lds_f64 *)lds; tDg = tTa + 32; tMom = (__attribute__((address_space(3))) int *)(tDg + 96); lo = 32 + 96 + 48;
+        hp = (lds_f64 *)(lds + lo); lo += hNPp;
+        for (int d = 0; d < A.dim; ++d) { hc[d] = (lds_f64 *)(lds + lo); lo += hNPp; }
+        for (int d = 0; d < A.dim; ++d) { hL[d] = (lds_f64 *)(lds + lo); lo += 2 * hPC; }
+        for (int d = 0; d < A.dim; ++d) { hD[d] = (lds_f64 *)(lds + lo); lo += (A.nlines[d] + 1) & ~1L; }
+        if (tid < 27) { const int d = tid / 9, m = tid % 9; tTa[tid] = A.mt[d].n > 1 ? A.mt[d].Ta[m] : A.ma[d].Ta; }
+        if (tid < 81) { tDg[tid] = A.diagc[tid / 3][tid % 3]; tMom[tid] = A.mom[tid / 27][(tid / 3) % 9][tid % 3]; }
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int j = tid + k * 512, mo = j / hPC, ip = j - mo * hPC, row = ip / nxp, ix = ip - row * nxp;
+            gj[k] = (j < hNPp && ip < hNp && ix < A.G.nx) ? mo * (int)N + row * A.G.nx + ix : -1;
+            if (j < hNPp) { hp[j] = 0.0; hc[0][j] = 0.0; if (A.dim >= 2) hc[1][j] = 0.0; if (A.dim == 3) hc[2][j] = 0.0; }
+        }
+        __syncthreads();
     }
     double *const wp = vp ? vp : A.p, *const wq = vq ? vq : A.q, *const wr = vr ? vr : A.r;
     double keff = A.keff0;
@@ -1683,6 +1800,218 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
         const double prod_old = block_total(s, sred);
         const double inv_k = 1.0 / keff;
         for (int g = 0; g < ng; ++g) {
+            if constexpr (SERH) {
+                double *const graw = A.raw + (long)g * NP;
+                double rv[KD], xv[KD], cv[KD], pv[KD];
+                const int nx = A.G.nx, ny = A.G.ny, n_ = (int)N;
+                // this group's factors and first pivots
+#pragma unroll
+                for (int d = 0; d < 3; ++d) if (d < A.dim) {
+                    for (int ip = tid; ip < hPC; ip += nt) {
+                        const int row = ip / nxp, ix = ip - row * nxp;
+                        const bool ok = ip < hNp && ix < nx;
+                        const long e = g * N + row * nx + ix;
+                        hL[d][ip] = ok ? A.L[d][e] : 0.0; hL[d][hPC + ip] = ok ? A.DR[d][e] : 0.0;
+                    }
+                    for (int i = tid; i < (int)A.nlines[d]; i += nt) hD[d][i] = A.D0[d][g * A.nlines[d] + i];
+                }
+                // rhs (:1716-1726), CG start (src/solvers.cpp:583-592); C diagonal + the bubbles' diagonal terms of every direction
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < KD; ++k) {
+                    double v = 0.0; cv[k] = 0.0;
+                    if (gj[k] >= 0) {
+                        const int i = gj[k], mo = i / n_, e = i - mo * n_;
+                        const double chv = A.Chi[g * N + e] * inv_k;
+                        v = fabs(chv) < 1e-14 ? 0.0 : chv * A.tf[i];
+                        for (int gp = 0; gp < ng; ++gp) {
+                            const double *M = A.Ms[g * ng + gp];
+                            if (gp == g || !M) continue;
+                            v += M[i] * (gp < g ? A.raw : A.phi)[gp * NP + i];
+                        }
+                        const int ex = e % nx, ey = (e / nx) % ny, ez = e / (nx * ny);
+                        const double Dc = A.ma[0].D[g * N + e];
+                        double cd = A.Cd0[g * NP + i];
+                        for (int d = 0; d < A.dim; ++d) { const double f = tDg[mo * 3 + d]; if (f != 0.0) cd += f * (Dc / geom_factor(A.G, d, ex, ey, ez)); }
+                        cv[k] = cd;
+                    }
+                    rv[k] = v; pv[k] = v; xv[k] = 0.0; s += v * v;
+                    if (tid + k * 512 < hNPp) hp[tid + k * 512] = v;
+                }
+                double rr = block_total(s, sred);
+                const double rhs_norm = sqrt(rr), tol_sq = A.cg_tol * A.cg_tol * rhs_norm * rhs_norm;
+                int its = 0;
+                HiConst hcst;
+                for (int l = 0; l < 2; ++l) { hcst.eL[l] = A.ma[0].eL[l]; hcst.eR[l] = A.ma[0].eR[l]; hcst.Gc[l] = A.ma[0].Gc[l]; }
+                const int nm = A.nmodes;
+                while (its < A.cg_max) {
+#ifdef NF_STAMPS
+                    long long ts0 = (long long)__builtin_readcyclecounter();
+#endif
+                    // ---- every (direction, transverse mode, line) at once, one lane each
+                    for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
+                        const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
+                        const int nl = d == 0 ? (int)A.nlines[0] : d == 1 ? (int)A.nlines[1] : (int)A.nlines[2];
+                        const int rem = sl_ - (d == 0 ? A.slot0[0] : d == 1 ? A.slot0[1] : A.slot0[2]);
+                        const int mode = rem / nl, l = rem - mode * nl;
+                        if (mode < nm) {
+                            const int m0 = tMom[(d * 9 + mode) * 3], o1 = (tMom[(d * 9 + mode) * 3 + 1] - m0) * hPC, o2 = NB > 1 ? (tMom[(d * 9 + mode) * 3 + 2] - m0) * hPC : 0;
+                            const int base = d == 0 ? l * nxp : d == 1 ? (l / nx) * nxp * ny + l % nx : (l / nx) * nxp + l % nx;
+                            const int sl = d == 0 ? 1 : d == 1 ? nxp : nxp * ny, n = d == 0 ? nx : d == 1 ? ny : A.G.nz;
+                            lds_f64 *const cd_ = d == 0 ? hc[0] : d == 1 ? hc[1] : hc[2];
+                            const lds_f64 *const Ld = d == 0 ? hL[0] : d == 1 ? hL[1] : hL[2], *const Dd = d == 0 ? hD[0] : d == 1 ? hD[1] : hD[2];
+                            serial_line_hi<NB>(hp + m0 * hPC + base, o1, o2, Ld + base, hPC, cd_ + m0 * hPC + base, Dd[l], tTa[d * 9 + mode], hcst, n, sl);
+                        }
+                    }
+                    __syncthreads();
+#ifdef NF_STAMPS
+                    long long ts1 = (long long)__builtin_readcyclecounter();
+#endif
+                    double qv[KD], dot = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) {
+                        const int j = tid + k * 512; const bool in = j < hNPp;
+                        const int jj = in ? j : 0;
+                        double q_ = cv[k] * pv[k] + hc[0][jj];
+                        if (A.dim >= 2) q_ += hc[1][jj];
+                        if (A.dim == 3) q_ += hc[2][jj];
+                        qv[k] = in ? q_ : 0.0; dot += pv[k] * qv[k];
+                    }
+#ifdef NF_STAMPS
+                    long long ts2 = (long long)__builtin_readcyclecounter();
+#endif
+                    const double pq = block_total_1b(dot, sred, 0);   // src/solvers.cpp:602-606
+#ifdef NF_STAMPS
+                    long long ts3 = (long long)__builtin_readcyclecounter();
+#endif
+                    if (fabs(pq) < 1e-30) break;
+                    const double alpha = rr / pq;
+                    s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) { rv[k] = rv[k] - alpha * qv[k]; s += rv[k] * rv[k]; }
+                    const double rr_new = block_total_1b(s, sred, 1);   // :613-631
+                    ++its;
+                    const bool conv = rr_new < tol_sq;
+                    const double beta = rr_new / rr; rr = rr_new;
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) {                // :609, :630
+                        xv[k] = fma(alpha, pv[k], xv[k]);
+                        pv[k] = fma(beta, pv[k], rv[k]);
+                        if (tid + k * 512 < hNPp) hp[tid + k * 512] = pv[k];
+                    }
+                    __syncthreads();
+#ifdef NF_STAMPS
+                    if (tid == 0 && A.hist) { long long ts4 = (long long)__builtin_readcyclecounter(); long long *acc = (long long *)(A.hist + 3 * A.max_outer);
+                                              acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1; }
+#endif
+                    if (conv) break;
+                }
+#pragma unroll
+                for (int k = 0; k < KD; ++k) if (gj[k] >= 0) graw[gj[k]] = xv[k];
+                if (tid == 0) A.hist_cg[it * ng + g] = its;
+                cg_total += its;
+                __syncthreads();
+                continue;
+            }
+            if constexpr (SERIAL) {
+                double *const graw = A.raw + (long)g * N;
+                double rv[KC], xv[KC], cv[KC], pv[KC];
+                // this group's factors into the directions' blocks, first pivots, C diagonal into registers
+#pragma unroll
+                for (int d = 0; d < 3; ++d) if (d < A.dim) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int ip = tid + k * 512;
+                        lb[d][ip] = gi[k] >= 0 ? A.L[d][g * N + gi[k]] : 0.0;
+                        lb[d][PITCH + ip] = gi[k] >= 0 ? A.DR[d][g * N + gi[k]] : 0.0;
+                    }
+                    for (int i = tid; i < (int)A.nlines[d]; i += nt) ((lds_f64 *)lD[d])[i] = A.D0[d][g * A.nlines[d] + i];
+                }
+                // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    double v = 0.0; cv[k] = 0.0;
+                    if (gi[k] >= 0) {
+                        const int i = gi[k];
+                        v = inv_k * (A.Chi[g * N + i] * A.tf[i]);
+                        for (int gp = 0; gp < ng; ++gp) {
+                            const double *M = A.Ms[g * ng + gp];
+                            if (gp == g || !M) continue;
+                            v += M[i] * (gp < g ? A.raw : A.phi)[gp * N + i];
+                        }
+                        cv[k] = A.Cd0[g * N + i];
+                    }
+                    rv[k] = v; pv[k] = v; xv[k] = 0.0; lp[tid + k * 512] = v; s += v * v;
+                }
+                double rr = block_total(s, sred);
+                const double rhs_norm = sqrt(rr), tol_sq = A.cg_tol * A.cg_tol * rhs_norm * rhs_norm;
+                int its = 0;
+                const int nx = A.G.nx, ny = A.G.ny;
+                while (its < A.cg_max) {
+#ifdef NF_STAMPS
+                    long long ts0 = (long long)__builtin_readcyclecounter();
+#endif
+                    // ---- every line of every direction at once, one lane each: X p, Y p, Z p into the directions' blocks
+                    for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
+                        const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
+                        const int l = sl_ - A.slot0[d];
+                        if (l < (int)A.nlines[d]) {
+                            if (d == 0) serial_line_rt0<PITCH>(lp, lb[0], lD[0][l], A.ma[0].Ta, nx, l * nxp, 1);
+                            else if (d == 1) serial_line_rt0<PITCH>(lp, lb[1], lD[1][l], A.ma[1].Ta, ny, (l / nx) * nxp * ny + l % nx, nxp);
+                            else serial_line_rt0<PITCH>(lp, lb[2], lD[2][l], A.ma[2].Ta, A.G.nz, (l / nx) * nxp + l % nx, nxp * ny);
+                        }
+                    }
+                    __syncthreads();
+#ifdef NF_STAMPS
+                    long long ts1 = (long long)__builtin_readcyclecounter();
+#endif
+                    // ---- own cells: q = C p + X p + Y p + Z p and p.q
+                    double qv[KC], dot = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int ip = tid + k * 512;
+                        double q_ = cv[k] * pv[k] + lb[0][2 * PITCH + ip];
+                        if (A.dim >= 2) q_ += lb[1][2 * PITCH + ip];
+                        if (A.dim == 3) q_ += lb[2][2 * PITCH + ip];
+                        qv[k] = q_; dot += pv[k] * q_;
+                    }
+#ifdef NF_STAMPS
+                    long long ts2 = (long long)__builtin_readcyclecounter();
+#endif
+                    const double pq = block_total_1b(dot, sred, 0);   // src/solvers.cpp:602-606
+#ifdef NF_STAMPS
+                    long long ts3 = (long long)__builtin_readcyclecounter();
+#endif
+                    if (fabs(pq) < 1e-30) break;
+                    const double alpha = rr / pq;
+                    s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) { rv[k] = rv[k] - alpha * qv[k]; s += rv[k] * rv[k]; }
+                    const double rr_new = block_total_1b(s, sred, 1);   // :613-631
+                    ++its;
+                    const bool conv = rr_new < tol_sq;
+                    const double beta = rr_new / rr; rr = rr_new;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {                // :609, :630
+                        xv[k] = fma(alpha, pv[k], xv[k]);
+                        pv[k] = fma(beta, pv[k], rv[k]);
+                        lp[tid + k * 512] = pv[k];
+                    }
+                    __syncthreads();
+#ifdef NF_STAMPS
+                    if (tid == 0 && A.hist) { long long ts4 = (long long)__builtin_readcyclecounter(); long long *acc = (long long *)(A.hist + 3 * A.max_outer);
+                                              acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1; }
+#endif
+                    if (conv) break;
+                }
+#pragma unroll
+                for (int k = 0; k < KC; ++k) if (gi[k] >= 0) graw[gi[k]] = xv[k];
+                if (tid == 0) A.hist_cg[it * ng + g] = its;
+                cg_total += its;
+                __syncthreads();
+                continue;
+            }
             double *const graw = A.raw + (long)g * NP;
             double *const xsol = vx ? vx : graw;
             // this group's line factors and C diagonal into LDS (when planned)
@@ -1692,10 +2021,6 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                 if (fR[d]) for (long i = tid; i < N; i += nt) fR[d][i] = A.DR[d][g * N + i];
             }
             if (fC) for (long i = tid; i < NP; i += nt) fC[i] = A.Cd0[g * NP + i];
-            if (SERIAL) for (int d = 0; d < A.dim; ++d) {
-                for (long i = tid; i < N; i += nt) { sblk[d][i] = A.L[d][g * N + i]; sblk[d][PITCH + i] = A.DR[d][g * N + i]; }
-                for (long i = tid; i < A.nlines[d]; i += nt) sD0[d][i] = A.D0[d][g * A.nlines[d] + i];
-            }
             // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
             s = 0.0;
             for (long i = tid; i < NP; i += nt) {
@@ -1725,67 +2050,6 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                 }
                 dL[d] = fL[d] ? fL[d] : A.L[d] + g * N; dR[d] = fR[d] ? fR[d] : A.DR[d] + g * N;
             }
-            if constexpr (SERIAL) {
-                const int nx = A.G.nx, nxy = A.G.nx * A.G.ny, n_ = (int)N;
-                lds_f64 *const lp = (lds_f64 *)vp, *const lr = (lds_f64 *)vr, *const lx = (lds_f64 *)vx, *const lC = (lds_f64 *)fC;
-                lds_f64 *const lb0 = (lds_f64 *)sblk[0], *const lb1 = (lds_f64 *)sblk[1], *const lb2 = (lds_f64 *)sblk[2];
-                const lds_f64 *const lD0 = (const lds_f64 *)sD0[0], *const lD1 = (const lds_f64 *)sD0[1], *const lD2 = (const lds_f64 *)sD0[2];
-                while (its < A.cg_max) {
-#ifdef NF_STAMPS
-                    long long ts0 = (long long)__builtin_readcyclecounter();
-#endif
-                    // ---- every line of every direction at once, one lane each: X p, Y p, Z p into the directions' blocks
-                    for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
-                        const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
-                        const int l = sl_ - A.slot0[d];
-                        if (l < (int)A.nlines[d]) {
-                            if (d == 0) serial_line_rt0<PITCH>(lp, lb0, lD0[l], mad[0].Ta, nx, l * nx, 1);
-                            else if (d == 1) serial_line_rt0<PITCH>(lp, lb1, lD1[l], mad[1].Ta, A.G.ny, (l / nx) * nxy + l % nx, nx);
-                            else serial_line_rt0<PITCH>(lp, lb2, lD2[l], mad[2].Ta, A.G.nz, l, nxy);
-                        }
-                    }
-                    __syncthreads();
-#ifdef NF_STAMPS
-                    long long ts1 = (long long)__builtin_readcyclecounter();
-#endif
-                    // ---- own cells (the same ones in every loop below: no barrier between them): q = C p + X p + Y p + Z p, p.q
-                    lds_f64 *const vq_ = lb0 + 2 * PITCH;
-                    double dot = 0.0;
-                    for (int i = tid; i < n_; i += nt) {
-                        const double pv = lp[i];
-                        double qv = lC[i] * pv + vq_[i];
-                        if (A.dim >= 2) qv += lb1[2 * PITCH + i];
-                        if (A.dim == 3) qv += lb2[2 * PITCH + i];
-                        vq_[i] = qv; dot += pv * qv;
-                    }
-#ifdef NF_STAMPS
-                    long long ts2 = (long long)__builtin_readcyclecounter();
-#endif
-                    const double pq = block_total_1b(dot, sred, 0);   // src/solvers.cpp:602-606
-#ifdef NF_STAMPS
-                    long long ts3 = (long long)__builtin_readcyclecounter();
-#endif
-                    if (fabs(pq) < 1e-30) break;
-                    alpha = rr / pq;
-                    s = 0.0;
-                    for (int i = tid; i < n_; i += nt) { const double rn = lr[i] - alpha * vq_[i]; lr[i] = rn; s += rn * rn; }
-                    const double rr_new = block_total_1b(s, sred, 1);   // :613-631
-                    ++its;
-                    const bool conv = rr_new < tol_sq;
-                    beta = rr_new / rr; rr = rr_new;
-                    for (int i = tid; i < n_; i += nt) {          // :609, :630
-                        const double pv = lp[i];
-                        lx[i] = fma(alpha, pv, lx[i]);
-                        if (!conv) lp[i] = fma(beta, pv, lr[i]);
-                    }
-                    __syncthreads();
-#ifdef NF_STAMPS
-                    if (tid == 0 && A.hist) { long long ts4 = (long long)__builtin_readcyclecounter(); long long *acc = (long long *)(A.hist + 3 * A.max_outer);
-                                              acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1; }
-#endif
-                    if (conv) break;
-                }
-            } else
             while (its < A.cg_max) {
                 const bool fuse = its > 0;
                 double dot = 0.0;
