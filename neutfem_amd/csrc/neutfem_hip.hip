@@ -122,7 +122,7 @@ struct nf_team {
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
     int opt_fuse3 = 1; long fuse3_max_cells = 4L << 20;   // fused-direction CG (two launches per iteration) up to this many cells
-    int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
+    int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, opt_resident_two_sided = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
     long direct_max_dofs = 2048;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group
@@ -1558,7 +1558,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
         CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
-        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
     double kc = 1.0; int nout = 0;
@@ -1953,9 +1953,9 @@ static bool resident_serial_fits(const nf_team *T, const nf_solver *S)
     const long cap = 160 * 1024 / 8 - 32;
     const long Np = (long)(S->nx | 1) * S->ny * S->nz;
     long lines = 0; for (int d = 0; d < S->dim; ++d) lines += (S->nlines[d] + 1) & ~1L;
-    if (S->nb == 0) { const long pitch = Np <= 1536 ? 1536 : 2560; return Np <= pitch && 64 + 16 + (1 + 3L * S->dim) * pitch + lines <= cap; }
+    if (S->nb == 0) { const long pitch = Np <= 1536 ? 1536 : 2560; return Np <= pitch && 64 + 16 + (1 + 3L * S->dim) * pitch + 3 * lines <= cap; }
     const long PC = (Np + 63) & ~63L, NPp = PC * S->nloc;
-    return NPp <= 5120 && n_modes(S) <= 9 && S->nloc <= 27 && 64 + 16 + 176 + (1 + S->dim) * NPp + 2L * S->dim * PC + lines <= cap;
+    return NPp <= 5120 && n_modes(S) <= 9 && S->nloc <= 27 && 64 + 16 + 176 + (1 + S->dim) * NPp + 2L * S->dim * PC + 3 * lines <= cap;
 }
 static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, const double *ca, const double *cbv, double sigma,
                                double cg_tol, int cg_max, double *keff_out)
@@ -1997,7 +1997,11 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
         const int pitch = Np <= 1536 ? 1536 : 2560;              // multiples of 512 (cells per thread) and of 64 (ds_read2st64)
         long need = 64 + 16 + (1 + 3L * S->dim) * pitch;
         int slot = 0;
-        for (int d = 0; d < S->dim; ++d) { need += (S->nlines[d] + 1) & ~1L; A.slot0[d] = slot; slot += (int)((S->nlines[d] + 63) / 64) * 64; }
+        for (int d = 0; d < S->dim; ++d) {
+            const int nd = d == 0 ? S->nx : d == 1 ? S->ny : S->nz;
+            A.tw[d] = (nd >= 4 && T->opt_resident_two_sided) ? 1 : 0;   // two lanes per line, meeting in the middle
+            need += 3 * ((S->nlines[d] + 1) & ~1L); A.slot0[d] = slot; slot += (int)((S->nlines[d] * (A.tw[d] ? 2 : 1) + 63) / 64) * 64;
+        }
         for (int d = S->dim; d < 4; ++d) A.slot0[d] = slot;
         if (Np <= pitch && need <= cap) {
             serial = true;
@@ -2015,7 +2019,11 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
         const int nm = n_modes(S);
         long need = 64 + 16 + 176 + (1 + S->dim) * NPp + 2L * S->dim * PC;
         int slot = 0;
-        for (int d = 0; d < S->dim; ++d) { need += (S->nlines[d] + 1) & ~1L; A.slot0[d] = slot; slot += (int)((S->nlines[d] * nm + 63) / 64) * 64; }
+        for (int d = 0; d < S->dim; ++d) {
+            const int nd = d == 0 ? S->nx : d == 1 ? S->ny : S->nz;
+            A.tw[d] = (nd >= 4 && T->opt_resident_two_sided) ? 1 : 0;
+            need += 3 * ((S->nlines[d] + 1) & ~1L); A.slot0[d] = slot; slot += (int)((S->nlines[d] * nm * (A.tw[d] ? 2 : 1) + 63) / 64) * 64;
+        }
         for (int d = S->dim; d < 4; ++d) A.slot0[d] = slot;
         if (NPp <= 5120 && nm <= 9 && S->nloc <= 27 && need <= cap) {
             serial = true;
@@ -2493,6 +2501,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "resident")) T->opt_resident = value != 0;
     else if (!strcmp(key, "resident_lds")) T->opt_resident_lds = value != 0;
     else if (!strcmp(key, "resident_serial")) T->opt_resident_serial = value != 0;
+    else if (!strcmp(key, "resident_two_sided")) T->opt_resident_two_sided = value != 0;
     else if (!strcmp(key, "resident_max_dofs")) { T->resident_max_dofs = value; T->resident_serial_max_dofs = std::min<long>(value, 5120); }   // one knob caps both variants
     else if (!strcmp(key, "resident_serial_max_dofs")) T->resident_serial_max_dofs = value;
     else if (!strcmp(key, "direct_max_dofs")) T->direct_max_dofs = std::max(0L, std::min(8192L, value));

@@ -1538,7 +1538,7 @@ struct ResidentArgs {
     const double *Cd0; int lds_mask;
     // RT0-P0 "line per lane" variant (k_resident_keff<.., 0, true>): lane slots of the directions (each direction starts on a wavefront
     // boundary), and two spare vectors for the y / z contributions should they not fit in LDS (they always do under the host's plan)
-    int slot0[4];
+    int slot0[4], tw[3];                                         // tw: two lanes per line in that direction (lines of >= 4 cells)
     // the same for RT_k-P_m with bubble moments (k_resident_keff<.., NB > 0, -1>): cell pitch, the moment index of every (direction,
     // transverse mode, along-index), and per (moment, direction) the factor T_a G_l^2 / M^bb_l of the bubble's diagonal term (0 when
     // the moment has no bubble in that direction), which is folded into the C diagonal once per group
@@ -1599,25 +1599,76 @@ __device__ __forceinline__ void serial_bwd(lds_f64 *&bp, int sl, double Ta, doub
         u2 = u1; Ln = Lv[i];
     }
 }
+// Two lanes per line ("burn at both ends"): the even lane eliminates from face 0 up to the middle face k = n / 2, the odd lane -- on the
+// mirrored line, with the factors of the mirrored elimination in its cells' slots (serial_twist_factors) -- from face n down to it; they
+// meet in u_k = (b_k - l_{k-1} z_{k-1} - l~ z~) / d'_k and substitute outwards.  Mirroring turns b into -b and u into -u, the outputs
+// T_a (u_{c+1} - u_c) come out the same, so both lanes run the same code with `cnt` own cells, a stride of opposite sign and their own
+// first pivot.  Half the dependent chain, half the instructions per wavefront.
+__device__ __forceinline__ double quad_swap(double v)            // value of the partner lane (lane ^ 1)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pair_even(double v)            // value of the even lane of the pair
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xA0, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xA0, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 template <int PITCH>
-__device__ __forceinline__ void serial_line_rt0(const lds_f64 *x, lds_f64 *blk, double d0, double Ta, int n, int base, int sl)
+__device__ __forceinline__ void serial_line_rt0(const lds_f64 *x, lds_f64 *blk, double d0, double dm, double Ta, int cnt, int base, int sl,
+                                                bool two_sided, bool top)
 {
     const lds_f64 *xp = x + base; lds_f64 *bp = blk + base;
     double xc = xp[0], z = -xc;
     const double w0 = z * d0;
-    const int m = n - 1;
+    const int m = cnt - 1;
     for (int k = 0; k < (m >> 3); ++k) serial_fwd<8, PITCH>(xp, bp, sl, z, xc);
     if (m & 4) serial_fwd<4, PITCH>(xp, bp, sl, z, xc);
     if (m & 2) serial_fwd<2, PITCH>(xp, bp, sl, z, xc);
     if (m & 1) serial_fwd<1, PITCH>(xp, bp, sl, z, xc);
-    z = xc - bp[0] * z;                                          // the last cell: nothing above it
-    double u2 = z * bp[PITCH], Ln = bp[0];                       // u_n = w_n (L_n = 0)
+    double Ln = bp[0], u2;
+    if (two_sided) {
+        const double Pown = Ln * z, b = xc - xp[sl];             // xp[sl]: the partner's last cell
+        const double Poth = quad_swap(Pown);
+        const double um = ((b + Poth) - Pown) * dm;
+        const double ut = pair_even(um);                         // one value for both halves
+        u2 = top ? ut : -ut;
+    } else {
+        z = xc - Ln * z;                                         // the last cell: nothing above it
+        u2 = z * bp[PITCH];                                      // u_n = w_n (L_n = 0)
+    }
     if (m & 1) serial_bwd<1, PITCH>(bp, sl, Ta, u2, Ln);
     if (m & 2) serial_bwd<2, PITCH>(bp, sl, Ta, u2, Ln);
     if (m & 4) serial_bwd<4, PITCH>(bp, sl, Ta, u2, Ln);
     for (int k = 0; k < (m >> 3); ++k) serial_bwd<8, PITCH>(bp, sl, Ta, u2, Ln);
     const double u0 = w0 - Ln * u2;
     bp[2 * PITCH] = Ta * (u2 - u0);
+}
+// Factors of the mirrored elimination for the upper part of a line (cells k .. n-1), from the stored top-down factors: d_f = 1 / (1/d_f),
+// e_c = l_c d_c, t_f = d_f + l_{f-1} e_{f-1}; then d^_n = t_n, l~_f = e_f / d^_{f+1}, d^_f = t_f - l~_f e_f downwards.  Cell c gets l~_c in
+// its L slot and 1 / d^_c in its 1/d slot (what the mirrored sweep expects there); returns 1 / d^_n, and 1 / d'_k of the middle face
+// (d'_k = d_k - l~_k e_k) through dm.  L: the line's first cell, oR: offset of the 1/d slots.
+__device__ __forceinline__ double serial_twist_factors(lds_f64 *L, int oR, double d0inv, int n, int k, int sl, double &dm)
+{
+    auto dpiv = [&](int f) { return 1.0 / (f == 0 ? d0inv : (double)L[(f - 1) * sl + oR]); };   // standard pivot of face f
+    double dlo = dpiv(n - 1), elo = L[(n - 1) * sl] * dlo;       // d_{n-1}, e_{n-1}
+    double dhat = dpiv(n) + L[(n - 1) * sl] * elo;               // t_n
+    const double first = 1.0 / dhat;
+    for (int f = n - 1; f > k; --f) {                            // face f: cell f holds l~_f and 1 / d^_f
+        const double dlo2 = dpiv(f - 1), elo2 = L[(f - 1) * sl] * dlo2;
+        const double tf = dlo + L[(f - 1) * sl] * elo2;
+        const double lt = elo / dhat;
+        L[f * sl] = lt;
+        dhat = tf - lt * elo;
+        L[f * sl + oR] = 1.0 / dhat;
+        dlo = dlo2; elo = elo2;
+    }
+    const double lk = elo / dhat;                                // dlo = d_k, elo = e_k here
+    L[k * sl] = lk;
+    dm = 1.0 / (dlo - lk * elo);
+    return first;
 }
 // The same for RT_k-P_m with NB bubble moments (formulas above ModeArgs).  x / y: moment 0 of the line's transverse mode at the first cell,
 // o1 / o2: offsets of the along-moments 1 and 2; L at the first cell, 1/d at offset oR.  The bubbles' own diagonal term
@@ -1670,21 +1721,34 @@ __device__ __forceinline__ void hi_bwd(const lds_f64 *&Lp, lds_f64 *&yp, int o1,
         u2 = u1; Ln = Lv[i];
     }
 }
+// cnt own cells; two_sided: see serial_line_rt0 -- the mirrored half sees the odd along-moment with the opposite sign, which is the
+// caller's business (HiConst::Gc[0] negated: it multiplies x_1 on the way in and y_1 on the way out)
 template <int NB>
-__device__ __forceinline__ void serial_line_hi(const lds_f64 *x, int o1, int o2, const lds_f64 *L, int oR, lds_f64 *y, double d0, double Ta,
-                                               const HiConst &c, int n, int sl)
+__device__ __forceinline__ void serial_line_hi(const lds_f64 *x, int o1, int o2, const lds_f64 *L, int oR, lds_f64 *y, double d0, double dm, double Ta,
+                                               const HiConst &c, int cnt, int sl, bool two_sided, bool top)
 {
     const lds_f64 *xp = x + sl, *Lp = L; lds_f64 *wp = y;
     double xL0, xRc;
     hi_faces<NB>(x[0], NB > 0 ? x[o1] : 0.0, NB > 1 ? x[o2] : 0.0, c, xL0, xRc);
     double z = -xL0;
     const double w0 = z * d0;
-    const int m = n - 1;
+    const int m = cnt - 1;
     for (int k = 0; k < (m >> 2); ++k) hi_fwd<4, NB>(xp, o1, o2, Lp, oR, wp, sl, z, xRc, c);
     if (m & 2) hi_fwd<2, NB>(xp, o1, o2, Lp, oR, wp, sl, z, xRc, c);
     if (m & 1) hi_fwd<1, NB>(xp, o1, o2, Lp, oR, wp, sl, z, xRc, c);
-    z = xRc - Lp[0] * z;                                         // the last cell: nothing above it
-    double u2 = z * Lp[oR], Ln = Lp[0];
+    double Ln = Lp[0], u2;
+    if (two_sided) {
+        double xLn, xRn;
+        hi_faces<NB>(xp[0], NB > 0 ? xp[o1] : 0.0, NB > 1 ? xp[o2] : 0.0, c, xLn, xRn);   // the partner's last cell, seen from this side
+        const double Pown = Ln * z, b = xRc - xLn;
+        const double Poth = quad_swap(Pown);
+        const double um = ((b + Poth) - Pown) * dm;
+        const double ut = pair_even(um);
+        u2 = top ? ut : -ut;
+    } else {
+        z = xRc - Ln * z;                                        // the last cell: nothing above it
+        u2 = z * Lp[oR];
+    }
     lds_f64 *yp = wp;
     if (m & 1) hi_bwd<1, NB>(Lp, yp, o1, o2, sl, Ta, u2, Ln, c);
     if (m & 2) hi_bwd<2, NB>(Lp, yp, o1, o2, sl, Ta, u2, Ln, c);
@@ -1745,12 +1809,16 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
     // the mesh hold zeros everywhere, so nothing below is predicated.
     constexpr int KC = SERIAL ? PITCH / 512 : 1;
     lds_f64 *lp = nullptr, *lb[3] = { nullptr, nullptr, nullptr }; const lds_f64 *lD[3] = { nullptr, nullptr, nullptr };
+    lds_f64 *lDm[3] = { nullptr, nullptr, nullptr }, *lDr[3] = { nullptr, nullptr, nullptr };   // 1 / d'_k and 1 / d^_n per line (two-sided sweeps)
     int gi[KC], nxp = 0;
     if (SERIAL) {
         nxp = A.G.nx | 1;
         lp = (lds_f64 *)lds; lo = PITCH;
         for (int d = 0; d < A.dim; ++d) { lb[d] = (lds_f64 *)(lds + lo); lo += 3 * PITCH; }
-        for (int d = 0; d < A.dim; ++d) { lD[d] = (const lds_f64 *)(lds + lo); lo += (A.nlines[d] + 1) & ~1L; }
+        for (int d = 0; d < A.dim; ++d) {
+            const long nl2 = (A.nlines[d] + 1) & ~1L;
+            lD[d] = (const lds_f64 *)(lds + lo); lDm[d] = (lds_f64 *)(lds + lo + nl2); lDr[d] = (lds_f64 *)(lds + lo + 2 * nl2); lo += 3 * nl2;
+        }
         const int Np = nxp * A.G.ny * A.G.nz;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
@@ -1765,6 +1833,7 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
     // kernel argument would move the whole argument struct to scratch.  Every thread owns the DOFs tid + 512 k, k < KD.
     constexpr int KD = SERH ? 10 : 1;
     lds_f64 *hp = nullptr, *hc[3] = { nullptr, nullptr, nullptr }, *hL[3] = { nullptr, nullptr, nullptr }, *hD[3] = { nullptr, nullptr, nullptr };
+    lds_f64 *hDm[3] = { nullptr, nullptr, nullptr }, *hDr[3] = { nullptr, nullptr, nullptr };
     lds_f64 *tTa = nullptr, *tDg = nullptr; __attribute__((address_space(3))) int *tMom = nullptr;
     int gj[KD], hPC = 0, hNPp = 0, hNp = 0;
     if (SERH) {
@@ -1774,7 +1843,10 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
         hp = (lds_f64 *)(lds + lo); lo += hNPp;
         for (int d = 0; d < A.dim; ++d) { hc[d] = (lds_f64 *)(lds + lo); lo += hNPp; }
         for (int d = 0; d < A.dim; ++d) { hL[d] = (lds_f64 *)(lds + lo); lo += 2 * hPC; }
-        for (int d = 0; d < A.dim; ++d) { hD[d] = (lds_f64 *)(lds + lo); lo += (A.nlines[d] + 1) & ~1L; }
+        for (int d = 0; d < A.dim; ++d) {
+            const long nl2 = (A.nlines[d] + 1) & ~1L;
+            hD[d] = (lds_f64 *)(lds + lo); hDm[d] = hD[d] + nl2; hDr[d] = hD[d] + 2 * nl2; lo += 3 * nl2;
+        }
         if (tid < 27) { const int d = tid / 9, m = tid % 9; tTa[tid] = A.mt[d].n > 1 ? A.mt[d].Ta[m] : A.ma[d].Ta; }
         if (tid < 81) { tDg[tid] = A.diagc[tid / 3][tid % 3]; tMom[tid] = A.mom[tid / 27][(tid / 3) % 9][tid % 3]; }
 #pragma unroll
@@ -1815,6 +1887,18 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                     }
                     for (int i = tid; i < (int)A.nlines[d]; i += nt) hD[d][i] = A.D0[d][g * A.nlines[d] + i];
                 }
+                // two-sided directions: mirrored factors for the upper half of every line (one thread per line; the modes share them)
+                __syncthreads();
+#pragma unroll
+                for (int d = 0; d < 3; ++d) if (d < A.dim && A.tw[d]) {
+                    for (int l = tid; l < (int)A.nlines[d]; l += nt) {
+                        const int base = d == 0 ? l * nxp : d == 1 ? (l / nx) * nxp * ny + l % nx : (l / nx) * nxp + l % nx;
+                        const int sl = d == 0 ? 1 : d == 1 ? nxp : nxp * ny, n = d == 0 ? nx : d == 1 ? ny : A.G.nz;
+                        double dm;
+                        hDr[d][l] = serial_twist_factors(hL[d] + base, hPC, hD[d][l], n, n / 2, sl, dm);
+                        hDm[d][l] = dm;
+                    }
+                }
                 // rhs (:1716-1726), CG start (src/solvers.cpp:583-592); C diagonal + the bubbles' diagonal terms of every direction
                 double s = 0.0;
 #pragma unroll
@@ -1844,23 +1928,45 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                 HiConst hcst;
                 for (int l = 0; l < 2; ++l) { hcst.eL[l] = A.ma[0].eL[l]; hcst.eR[l] = A.ma[0].eR[l]; hcst.Gc[l] = A.ma[0].Gc[l]; }
                 const int nm = A.nmodes;
+                // which (direction, mode, line half) a lane slot sweeps; slot `tid` is decoded once per group
+                struct LaneLine { bool ok, tw, top; int cnt, sl, o1, o2; double d0, dm, Ta; const lds_f64 *x, *L; lds_f64 *y; HiConst c; };
+                auto lane_line = [&](int sl_) -> LaneLine {
+                    LaneLine o; o.ok = false; o.tw = o.top = false; o.cnt = o.sl = o.o1 = o.o2 = 0; o.d0 = o.dm = o.Ta = 0.0; o.x = o.L = hp; o.y = hc[0]; o.c = hcst;
+                    if (sl_ >= A.slot0[3]) return o;
+                    const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
+                    const int nl = d == 0 ? (int)A.nlines[0] : d == 1 ? (int)A.nlines[1] : (int)A.nlines[2];
+                    const int twd = d == 0 ? A.tw[0] : d == 1 ? A.tw[1] : A.tw[2];
+                    const int rem = sl_ - (d == 0 ? A.slot0[0] : d == 1 ? A.slot0[1] : A.slot0[2]);
+                    const int lane_l = twd ? rem >> 1 : rem;
+                    const int mode = lane_l / nl, l = lane_l - mode * nl;
+                    if (mode >= nm) return o;
+                    o.ok = true; o.tw = twd != 0; o.top = !twd || !(rem & 1);
+                    const int m0 = tMom[(d * 9 + mode) * 3];
+                    o.o1 = (tMom[(d * 9 + mode) * 3 + 1] - m0) * hPC; o.o2 = NB > 1 ? (tMom[(d * 9 + mode) * 3 + 2] - m0) * hPC : 0;
+                    const int base0 = d == 0 ? l * nxp : d == 1 ? (l / nx) * nxp * ny + l % nx : (l / nx) * nxp + l % nx;
+                    const int sl0 = d == 0 ? 1 : d == 1 ? nxp : nxp * ny, n = d == 0 ? nx : d == 1 ? ny : A.G.nz;
+                    o.cnt = !twd ? n : o.top ? n / 2 : n - n / 2; o.sl = o.top ? sl0 : -sl0;
+                    const int base = o.top ? base0 : base0 + (n - 1) * sl0;
+                    o.x = hp + m0 * hPC + base; o.L = (d == 0 ? hL[0] : d == 1 ? hL[1] : hL[2]) + base; o.y = (d == 0 ? hc[0] : d == 1 ? hc[1] : hc[2]) + m0 * hPC + base;
+                    o.d0 = o.top ? (d == 0 ? hD[0] : d == 1 ? hD[1] : hD[2])[l] : (d == 0 ? hDr[0] : d == 1 ? hDr[1] : hDr[2])[l];
+                    o.dm = twd ? (d == 0 ? hDm[0] : d == 1 ? hDm[1] : hDm[2])[l] : 0.0;
+                    o.Ta = tTa[d * 9 + mode];
+                    if (!o.top) o.c.Gc[0] = -o.c.Gc[0];          // mirrored line: the odd along-moment changes sign
+                    return o;
+                };
+                const LaneLine my = lane_line(tid);
                 while (its < A.cg_max) {
 #ifdef NF_STAMPS
                     long long ts0 = (long long)__builtin_readcyclecounter();
 #endif
-                    // ---- every (direction, transverse mode, line) at once, one lane each
-                    for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
-                        const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
-                        const int nl = d == 0 ? (int)A.nlines[0] : d == 1 ? (int)A.nlines[1] : (int)A.nlines[2];
-                        const int rem = sl_ - (d == 0 ? A.slot0[0] : d == 1 ? A.slot0[1] : A.slot0[2]);
-                        const int mode = rem / nl, l = rem - mode * nl;
-                        if (mode < nm) {
-                            const int m0 = tMom[(d * 9 + mode) * 3], o1 = (tMom[(d * 9 + mode) * 3 + 1] - m0) * hPC, o2 = NB > 1 ? (tMom[(d * 9 + mode) * 3 + 2] - m0) * hPC : 0;
-                            const int base = d == 0 ? l * nxp : d == 1 ? (l / nx) * nxp * ny + l % nx : (l / nx) * nxp + l % nx;
-                            const int sl = d == 0 ? 1 : d == 1 ? nxp : nxp * ny, n = d == 0 ? nx : d == 1 ? ny : A.G.nz;
-                            lds_f64 *const cd_ = d == 0 ? hc[0] : d == 1 ? hc[1] : hc[2];
-                            const lds_f64 *const Ld = d == 0 ? hL[0] : d == 1 ? hL[1] : hL[2], *const Dd = d == 0 ? hD[0] : d == 1 ? hD[1] : hD[2];
-                            serial_line_hi<NB>(hp + m0 * hPC + base, o1, o2, Ld + base, hPC, cd_ + m0 * hPC + base, Dd[l], tTa[d * 9 + mode], hcst, n, sl);
+                    // ---- every (direction, transverse mode, line) at once, one lane or a pair of lanes each
+                    {
+                        LaneLine o = my;
+                        for (int sl_ = tid;;) {                  // one call site: slot tid from the registers, any further slot decoded on the way
+                            if (o.ok) serial_line_hi<NB>(o.x, o.o1, o.o2, o.L, hPC, o.y, o.d0, o.dm, o.Ta, o.c, o.cnt, o.sl, o.tw, o.top);
+                            sl_ += nt;
+                            if (sl_ >= A.slot0[3]) break;
+                            o = lane_line(sl_);
                         }
                     }
                     __syncthreads();
@@ -1927,6 +2033,25 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                     }
                     for (int i = tid; i < (int)A.nlines[d]; i += nt) ((lds_f64 *)lD[d])[i] = A.D0[d][g * A.nlines[d] + i];
                 }
+                const int nx = A.G.nx, ny = A.G.ny;
+                // two-sided directions: the odd lane of every pair rewrites the upper half of its line with the mirrored factors
+                __syncthreads();
+                for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
+                    const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
+                    const int rem = sl_ - (d == 0 ? A.slot0[0] : d == 1 ? A.slot0[1] : A.slot0[2]);
+                    const int twd = d == 0 ? A.tw[0] : d == 1 ? A.tw[1] : A.tw[2], nl = d == 0 ? (int)A.nlines[0] : d == 1 ? (int)A.nlines[1] : (int)A.nlines[2];
+                    const int l = rem >> 1;
+                    if (twd && (rem & 1) && l < nl) {
+                        const int base = d == 0 ? l * nxp : d == 1 ? (l / nx) * nxp * ny + l % nx : (l / nx) * nxp + l % nx;
+                        const int sl = d == 0 ? 1 : d == 1 ? nxp : nxp * ny, n = d == 0 ? nx : d == 1 ? ny : A.G.nz;
+                        lds_f64 *const Lb = (d == 0 ? lb[0] : d == 1 ? lb[1] : lb[2]) + base;
+                        const lds_f64 *const D0d = d == 0 ? lD[0] : d == 1 ? lD[1] : lD[2];
+                        double dm;
+                        const double first = serial_twist_factors(Lb, PITCH, D0d[l], n, n / 2, sl, dm);
+                        (d == 0 ? lDm[0] : d == 1 ? lDm[1] : lDm[2])[l] = dm;
+                        (d == 0 ? lDr[0] : d == 1 ? lDr[1] : lDr[2])[l] = first;
+                    }
+                }
                 // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
                 double s = 0.0;
 #pragma unroll
@@ -1947,19 +2072,40 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
                 double rr = block_total(s, sred);
                 const double rhs_norm = sqrt(rr), tol_sq = A.cg_tol * A.cg_tol * rhs_norm * rhs_norm;
                 int its = 0;
-                const int nx = A.G.nx, ny = A.G.ny;
+                // which line (half) a lane slot sweeps; slot `tid` is decoded once per group, not once per iteration
+                struct LaneLine { bool ok, tw, top; int cnt, base, sl; double d0, dm, Ta; lds_f64 *blk; };
+                auto lane_line = [&](int sl_) -> LaneLine {
+                    LaneLine o; o.ok = false; o.tw = o.top = false; o.cnt = o.base = o.sl = 0; o.d0 = o.dm = o.Ta = 0.0; o.blk = lb[0];
+                    if (sl_ >= A.slot0[3]) return o;
+                    const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
+                    const int rem = sl_ - (d == 0 ? A.slot0[0] : d == 1 ? A.slot0[1] : A.slot0[2]);
+                    const int twd = d == 0 ? A.tw[0] : d == 1 ? A.tw[1] : A.tw[2], nl = d == 0 ? (int)A.nlines[0] : d == 1 ? (int)A.nlines[1] : (int)A.nlines[2];
+                    const int l = twd ? rem >> 1 : rem;
+                    if (l >= nl) return o;
+                    o.ok = true; o.tw = twd != 0; o.top = !twd || !(rem & 1);
+                    const int base0 = d == 0 ? l * nxp : d == 1 ? (l / nx) * nxp * ny + l % nx : (l / nx) * nxp + l % nx;
+                    const int sl0 = d == 0 ? 1 : d == 1 ? nxp : nxp * ny, n = d == 0 ? nx : d == 1 ? ny : A.G.nz;
+                    o.cnt = !twd ? n : o.top ? n / 2 : n - n / 2;
+                    o.base = o.top ? base0 : base0 + (n - 1) * sl0; o.sl = o.top ? sl0 : -sl0;
+                    o.Ta = d == 0 ? A.ma[0].Ta : d == 1 ? A.ma[1].Ta : A.ma[2].Ta;
+                    o.blk = d == 0 ? lb[0] : d == 1 ? lb[1] : lb[2];
+                    o.d0 = o.top ? (d == 0 ? lD[0] : d == 1 ? lD[1] : lD[2])[l] : (d == 0 ? lDr[0] : d == 1 ? lDr[1] : lDr[2])[l];
+                    o.dm = twd ? (d == 0 ? lDm[0] : d == 1 ? lDm[1] : lDm[2])[l] : 0.0;
+                    return o;
+                };
+                const LaneLine my = lane_line(tid);
                 while (its < A.cg_max) {
 #ifdef NF_STAMPS
                     long long ts0 = (long long)__builtin_readcyclecounter();
 #endif
-                    // ---- every line of every direction at once, one lane each: X p, Y p, Z p into the directions' blocks
-                    for (int sl_ = tid; sl_ < A.slot0[3]; sl_ += nt) {
-                        const int d = sl_ >= A.slot0[2] ? 2 : sl_ >= A.slot0[1] ? 1 : 0;
-                        const int l = sl_ - A.slot0[d];
-                        if (l < (int)A.nlines[d]) {
-                            if (d == 0) serial_line_rt0<PITCH>(lp, lb[0], lD[0][l], A.ma[0].Ta, nx, l * nxp, 1);
-                            else if (d == 1) serial_line_rt0<PITCH>(lp, lb[1], lD[1][l], A.ma[1].Ta, ny, (l / nx) * nxp * ny + l % nx, nxp);
-                            else serial_line_rt0<PITCH>(lp, lb[2], lD[2][l], A.ma[2].Ta, A.G.nz, (l / nx) * nxp + l % nx, nxp * ny);
+                    // ---- every line of every direction at once, one lane (or a pair of lanes) each: X p, Y p, Z p into the directions' blocks
+                    {
+                        LaneLine o = my;
+                        for (int sl_ = tid;;) {                  // one call site: slot tid from the registers, any further slot decoded on the way
+                            if (o.ok) serial_line_rt0<PITCH>(lp, o.blk, o.d0, o.dm, o.Ta, o.cnt, o.base, o.sl, o.tw, o.top);
+                            sl_ += nt;
+                            if (sl_ >= A.slot0[3]) break;
+                            o = lane_line(sl_);
                         }
                     }
                     __syncthreads();
