@@ -177,6 +177,7 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   "resident_serial" (default 1): meshes whose moments, factors and directions' contributions all fit in LDS run one lane per
  *   (direction, transverse mode, line) with serial sweeps instead of the segmented scans (nf_info "last_resident_serial"), up to
  *   "resident_serial_max_dofs" flux DOFs per group (default 5120, the structural limit; "resident_max_dofs" lowers it too);
+ *   "resident_two_sided" (default 1): lines of at least 4 cells are swept by two lanes that meet in the middle;
  *   "direct_max_dofs" (default 2048, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
  *   CG to 1e-14 stands in (nf_info "direct_standin_unconverged" counts group solves that did not get there);
  *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);

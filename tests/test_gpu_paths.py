@@ -26,7 +26,11 @@ def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
 
 @pytest.mark.parametrize("shape,rt,p,ng", [((24, 20, 6), 0, 0, 2), ((7, 6, 5), 0, 0, 3), ((19, 19, 1), 0, 0, 2), ((110, 1, 1), 1, 1, 2),
                                             ((12, 10, 1), 1, 1, 2), ((9, 8, 7), 1, 1, 2), ((10, 9, 1), 2, 2, 1), ((8, 6, 5), 2, 1, 2),
-                                            ((16, 14, 1), 1, 0, 2), ((40, 33, 3), 0, 0, 2)])
+                                            ((16, 14, 1), 1, 0, 2), ((40, 33, 3), 0, 0, 2),
+                                            # line-per-lane resident variant: lines of 4 cells (two cells per half), directions too short for
+                                            # the two-sided sweep next to long ones, more lane slots than threads, 1D, the wide-pitch instance
+                                            ((4, 8, 8), 0, 0, 2), ((9, 8, 3), 0, 0, 2), ((12, 11, 10), 0, 0, 2), ((150, 1, 1), 0, 0, 2),
+                                            ((47, 45, 1), 0, 0, 2), ((6, 3, 2), 1, 1, 2), ((21, 5, 1), 2, 2, 1)])
 def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     inp = synthetic_inputs(*shape, ng=ng, seed=7)
     tol = (1e-11, 1e-11, 1e-11, 1500, 3000)
