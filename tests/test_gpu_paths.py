@@ -29,7 +29,7 @@ def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
                                             ((16, 14, 1), 1, 0, 2), ((40, 33, 3), 0, 0, 2),
                                             # line-per-lane resident variant: lines of 4 cells (two cells per half), directions too short for
                                             # the two-sided sweep next to long ones, more lane slots than threads, 1D, the wide-pitch instance
-                                            ((4, 8, 8), 0, 0, 2), ((9, 8, 3), 0, 0, 2), ((12, 11, 10), 0, 0, 2), ((150, 1, 1), 0, 0, 2),
+                                            ((4, 8, 8), 0, 0, 2), ((9, 8, 3), 0, 0, 2), ((12, 11, 10), 0, 0, 2), ((250, 1, 1), 0, 0, 2),
                                             ((47, 45, 1), 0, 0, 2), ((6, 3, 2), 1, 1, 2), ((21, 5, 1), 2, 2, 1)])
 def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     inp = synthetic_inputs(*shape, ng=ng, seed=7)
@@ -38,6 +38,8 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     res = {}
     for name, opts, path in PATHS:
         r = res[name] = _run(inp, rt, p, tol, opts)
+        if name == "resident-scans" and shape[0] > 128:
+            path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
         assert r["path"] == path, (name, r["path"])
         assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
