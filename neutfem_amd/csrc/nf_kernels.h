@@ -1536,8 +1536,8 @@ struct ResidentArgs {
     // LDS residency (host plan, greedy by priority): bit 0 p, 1 q, 2 r, 3 x_sol, 4+2d L[d], 5+2d DR[d], 10 C diagonal.  One CU
     // moves ~10 B/cycle to and from L2 but 128 B/cycle to and from LDS, and a barrier no longer waits for global store acks.
     const double *Cd0; int lds_mask;
-    // RT0-P0 "line per lane" variant (k_resident_keff<.., 0, true>): lane slots of the directions (each direction starts on a wavefront
-    // boundary), and two spare vectors for the y / z contributions should they not fit in LDS (they always do under the host's plan)
+    // Line-per-lane variants (k_resident_keff<.., NB, PITCH != 0>): first lane slot of every direction (each direction starts on a
+    // wavefront boundary; slot0[3] = number of slots), and whether a direction's lines are swept by pairs of lanes
     int slot0[4], tw[3];                                         // tw: two lanes per line in that direction (lines of >= 4 cells)
     // the same for RT_k-P_m with bubble moments (k_resident_keff<.., NB > 0, -1>): cell pitch, the moment index of every (direction,
     // transverse mode, along-index), and per (moment, direction) the factor T_a G_l^2 / M^bb_l of the bubble's diagonal term (0 when
