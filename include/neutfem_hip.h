@@ -171,7 +171,7 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   "cg_lean" (default 1) lets the consumer of a reduction derive the CG scalars itself: no finalize launches on undivided meshes of at
  *   most "cg_lean_max_cells" cells (default 4 Mi; "cg_lean_grid" = blocks of the residual update), no k_cg_logic launches on slab teams;
  *   "cg_fuse3" (default 1) runs the x, y and z passes of an apply as ONE launch (two launches per CG iteration) on undivided meshes of
- *   at most "cg_fuse3_max_cells" cells (default 4 Mi);
+ *   at most "cg_fuse3_max_cells" cells (default 400 000: above, the four-launch lean iteration is faster);
  *   "resident" (default 1) runs the whole SolveKeff of an undivided mesh with at most "resident_max_dofs" flux DOFs per group (default
  *   2500) in one workgroup and one launch; "resident_lds" (default 1) keeps its CG vectors and factors in LDS as far as they fit;
  *   "resident_serial" (default 1): meshes whose moments, factors and directions' contributions all fit in LDS run one lane per
@@ -180,6 +180,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   "resident_two_sided" (default 1): lines of at least 4 cells are swept by two lanes that meet in the middle;
  *   "direct_max_dofs" (default 2048, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
  *   CG to 1e-14 stands in (nf_info "direct_standin_unconverged" counts group solves that did not get there);
+ *   "nt_loads" (default 1): on undivided RT0-P0 meshes of more than "nt_min_cells" cells (default 8 000 000: from there on the streams no longer live in the
+ *   256 MB memory-side cache between launches) the direction passes read their streams with non-temporal loads;
  *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
  *   "sep_fold" (default 1): slab teams form the separator values inside the accumulation pass of the z lines (no k_separators launch).
  * nf_info keys beyond the mesh sizes: "last_path" (0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel),

@@ -117,11 +117,15 @@ struct nf_team {
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     int cg_batch = 0;
+    // 192^3 (7.1 M cells): 229 -> 233 us per CG iteration with them, 224^3 (11.2 M): 389 -> 356, 256^3: 599 -> 550
+    int opt_nt_loads = 1; long nt_min_cells = 8000000;   // streaming (non-temporal) loads in the y / z passes of undivided meshes larger than this
     int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID, opt_sepfold = 1;
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
-    int opt_fuse3 = 1; long fuse3_max_cells = 4L << 20;   // fused-direction CG (two launches per iteration) up to this many cells
+    // fused-direction CG (two launches per iteration) up to this many cells.  Measured crossover against the four-launch lean path after
+    // the round-2 latency work: 64^3 19.1 vs 27.2 us per CG iteration, 80^3 39.1 vs 34.5, 128^3 77.7 vs 70.9, 160^3 221 vs 150
+    int opt_fuse3 = 1; long fuse3_max_cells = 400000;
     int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, opt_resident_two_sided = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
@@ -813,7 +817,9 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const CgFuse fz = (S->if_lo || S->if_hi) ? CgFuse{ nullptr, nullptr, nullptr } : S->fuse;   // slabs fuse in their endpoint pass instead
     const ModeTab mt = mode_tab(S, 0);
     const dim3 gr(grid, (unsigned)mt.n);                          // all transverse modes in one launch
-    if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
+    const bool nt = NB == 0 && vec && S->team->opt_nt_loads && N > S->team->nt_min_cells;   // streaming loads beyond the caches (per slab on teams)
+    if (nt) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB, NB == 0>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
+    else if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
     else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
 }
 template <int NB>
@@ -871,7 +877,10 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 16) * sizeof(double);
     const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
     const CgLean lz = (zmode == 1 && S->nloc == 1 && fz.p) ? S->lean_z1 : CgLean{ nullptr, nullptr, 0, 0, 0 };
+    // undivided meshes beyond the caches (the classic path's sizes): the variant with streaming loads (SF doubles as that flag for !SLAB)
+    const bool nt = zmode == 0 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;
 #define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (!SLABV && NBV == 0 && SEGV == 8 && nt) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, !SLABV && NBV == 0 && SEGV == 8>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); } while (0)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
         else if (SEG == 16 && NBV == 0) NF_S(16, DIRV, SLABV, 0); else if (SEG == 32 && NBV == 0) NF_S(32, DIRV, SLABV, 0); else return fail(NF_ERR_ARG, "bad s_seg"); } while (0)
@@ -2494,6 +2503,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
+    else if (!strcmp(key, "nt_loads")) T->opt_nt_loads = value != 0;
+    else if (!strcmp(key, "nt_min_cells")) T->nt_min_cells = value;
     else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
     else if (!strcmp(key, "cg_lean")) T->opt_lean = value != 0;
     else if (!strcmp(key, "sep_fold")) T->opt_sepfold = value != 0;

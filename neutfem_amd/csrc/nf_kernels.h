@@ -531,11 +531,24 @@ __global__ void k_diag_cache(Geom G, const double *__restrict__ D, const double 
 // a lane owns K consecutive cells per chunk of LPL*K cells, NCH chunks cover the line.
 //   forward  z_{c+1} = t_{c+1} - L[c] z_c, w = z * dinv ; backward u_f = w_f - L[f] u_{f+1}   (ModeArgs: t, outputs)
 // `first`: y_p = Cd_p x_p + ... (the x pass is the first to touch every moment), else accumulate.
+typedef double nf_d2 __attribute__((ext_vector_type(2)));
+template <bool NT = false>                                       // NT: streaming (non-temporal) loads, see ldg below
 __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, double &a, double &b, bool ok2)
 {
-    if (vec) { double2 v = make_double2(0, 0); if (ok) v = *reinterpret_cast<const double2 *>(p + i); a = v.x; b = v.y; }
+    if (vec) {
+        nf_d2 v = { 0.0, 0.0 };
+        if (ok) v = NT ? __builtin_nontemporal_load(reinterpret_cast<const nf_d2 *>(p + i)) : *reinterpret_cast<const nf_d2 *>(p + i);
+        a = v.x; b = v.y;
+    } else if (NT) { a = ok ? __builtin_nontemporal_load(p + i) : 0.0; b = ok2 ? __builtin_nontemporal_load(p + i + 1) : 0.0; }
     else { a = ok ? p[i] : 0.0; b = ok2 ? p[i + 1] : 0.0; }
 }
+// Streaming loads for the big-mesh passes: every array of a pass is larger than the caches and read once per pass, and a load that
+// carries the non-temporal hint does not push the lines the other streams still need out of L2 / MALL.  Tiled copy with the y / z
+// access pattern of the 256^3 passes, no arithmetic (scratch/tile_copy.hip, one MI355X): 4.99 -> 5.92 TB/s (y), 4.87 -> 6.07 (z);
+// non-temporal *stores* lose (5.00 / 4.88 alone, 5.40 / 5.54 combined).  Not for meshes that live in the caches between launches.
+template <bool NT>
+__device__ __forceinline__ double ldg(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
 // Fused CG (undivided mesh, any order: the x pass with all its transverse modes touches every moment exactly once): the
 // vector updates that follow FIN_RR -- x_sol += alpha p and p = r + beta p
 // (src/solvers.cpp:609,630) -- are deferred to the next iteration's x pass, which reads p anyway: p is read once instead
@@ -551,7 +564,7 @@ struct CgFuse { double *p; const double *r; double *xsol; double *pout; };
 // DPPS: cross-lane traffic of the scans through data-parallel primitives (VALU) instead of ds_bpermute (LDS crossbar).  That halves
 // the latency of a lone wave-task (resident kernel: 14.2 k -> 10.9 k cycles per x pass) but costs VALU issue slots: with many waves
 // per SIMD the crossbar version is faster (fused-direction launch at 128^3: 76.8 vs 82.9 us per CG iteration on the same box).
-template <int K, int NCH, bool VEC, int NB, class Mid = NoMid, bool DPPS = false>
+template <int K, int NCH, bool VEC, int NB, class Mid = NoMid, bool DPPS = false, bool NT = false>
 __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2, int first,
                                                long task, int lane, bool active, bool fuse, double f_alpha, double f_beta, const CgFuse &fz, Mid mid = Mid())
@@ -571,19 +584,19 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
         const bool ok = lv && c0 < nx, ok2 = lv && c0 + 1 < nx;
-        ld2(L, base + c0, ok, VEC, Ls[ch][0], Ls[ch][1], ok2);
-        ld2(DR, base + c0, ok, VEC, Rs[ch][0], Rs[ch][1], ok2);
+        ld2<NT>(L, base + c0, ok, VEC, Ls[ch][0], Ls[ch][1], ok2);
+        ld2<NT>(DR, base + c0, ok, VEC, Rs[ch][0], Rs[ch][1], ok2);
 #pragma unroll
         for (int q = 0; q <= NB; ++q) {
-            ld2(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
-            ld2(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
+            ld2<NT>(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
+            ld2<NT>(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
             if (fuse) {                                          // ma.x[q] points into p: the same offset addresses r and x_sol
                 const long mo = (ma.x[q] - fz.p) + base + c0;
-                ld2(fz.r, mo, ok, VEC, rq[q][ch][0], rq[q][ch][1], ok2);
-                ld2(fz.xsol, mo, ok, VEC, sq[q][ch][0], sq[q][ch][1], ok2);
+                ld2<NT>(fz.r, mo, ok, VEC, rq[q][ch][0], rq[q][ch][1], ok2);
+                ld2<NT>(fz.xsol, mo, ok, VEC, sq[q][ch][0], sq[q][ch][1], ok2);
             }
         }
-        if (NB > 0) ld2(ma.D, base + c0, ok, VEC, dq[NB > 0 ? ch : 0][0], dq[NB > 0 ? ch : 0][1], ok2);
+        if (NB > 0) ld2<NT>(ma.D, base + c0, ok, VEC, dq[NB > 0 ? ch : 0][0], dq[NB > 0 ? ch : 0][1], ok2);
     }
     if (mid(f_alpha, f_beta)) return 0.0;
     // ---- the deferred CG update of these cells, then the face values
@@ -702,7 +715,7 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
     return dot;
 }
 
-template <int K, int NCH, bool VEC, int NB>
+template <int K, int NCH, bool VEC, int NB, bool NT = false>
 __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                                                  const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
                                                  int first, int last, double *__restrict__ partials,
@@ -722,8 +735,8 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
         if (lean_on) stopped = lean_rr_step(lean, pre, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &fb);
         return stopped;
     };
-    const double dot = schur_x_task<K, NCH, VEC, NB>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first, (long)blockIdx.x * 4 + (threadIdx.x >> 6),
-                                                     threadIdx.x & 63, true, fuse, alpha0, beta0, fz, mid);
+    const double dot = schur_x_task<K, NCH, VEC, NB, decltype(mid), false, NT>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first, (long)blockIdx.x * 4 + (threadIdx.x >> 6),
+                                                                               threadIdx.x & 63, true, fuse, alpha0, beta0, fz, mid);
     if (stopped) return;                                         // decided inside, the same in every block: nothing to reduce
     if (last && partials) {
         const double s = block_sum(dot, sred);
@@ -768,6 +781,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
                                                const SlabArgs &sa, const CgFuse &fz, bool fuse, bool fro, double f_alpha, double f_beta, bool acc,
                                                long long *stamp = nullptr, Mid mid = Mid())
 {
+    constexpr bool NT = !SLAB && SF;                             // undivided big meshes: streaming loads (ldg)
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
@@ -841,11 +855,11 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     for (int i = 0; i <= SEG; ++i) {
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
-        xv[i] = ok ? x[a] : 0.0;
-        if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : x[a + roff]) : 0.0;
+        xv[i] = ok ? ldg<NT>(x + a) : 0.0;
+        if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : ldg<NT>(x + a + roff)) : 0.0;
         if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
-        Lv[i] = ok ? L[a] : 0.0;
-        if (i < SEG) Rv[i] = ok ? DR[a] : 0.0;
+        Lv[i] = ok ? ldg<NT>(L + a) : 0.0;
+        if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
         if (NB > 0) {
             v1a[i] = ok ? ma.x[1][a] : 0.0;
             if (NB > 1) v2a[NB > 1 ? i : 0] = ok ? ma.x[2][a] : 0.0;
@@ -944,7 +958,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     if (act) { sA2[si] = Q; sB2[si] = lu; }
     // y is only needed by the output stage: issue its loads here so they fly during the barrier + backward scan
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (acc && valid && c < n && wr) ? y[base + (long)c * sl] : 0.0; }
+    for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (acc && valid && c < n && wr) ? ldg<NT>(y + base + (long)c * sl) : 0.0; }
     double y1o[NB > 0 ? SEG : 1], y2o[NB > 1 ? SEG : 1];
     if (NB > 0) {
 #pragma unroll
@@ -1153,7 +1167,7 @@ struct Apply3 {
     int n[2], TX[2], NSEG[2], gx[2], gy[2]; long sl[2], ostride[2];   // y (index 0) and z (index 1) tiles
     long long *stamps;                  // diagnostic builds (-DNF_STAMPS): in-kernel cycle stamps of three blocks, else unused
 };
-template <int NCH, bool VEC, int NB, int SEG>
+template <int NCH, bool VEC, int NB, int SEG>                    // (streaming loads lose here at every size up to 4 Mi cells: 128^3 79 -> 91 us per CG iteration)
 __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, ModeArgs maz0, ModeTab mtx, ModeTab mty, ModeTab mtz, Geom G,
                                                 const double *__restrict__ Lx, const double *__restrict__ DRx, const double *__restrict__ D0x,
                                                 const double *__restrict__ Ly, const double *__restrict__ DRy, const double *__restrict__ D0y,
@@ -1302,7 +1316,7 @@ __global__ __launch_bounds__(256) void k_cg_rupdate(double *__restrict__ r, cons
     } else alpha = cg->alpha;
     double s = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-        const double rn = r[i] - alpha * q[i];
+        const double rn = r[i] - alpha * q[i];                   // (streaming loads change nothing here: 102.3 vs 102.9 us of non-pass time per iteration)
         r[i] = rn; s += rn * rn;
     }
     s = block_sum(s, sred);

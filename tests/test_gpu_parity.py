@@ -336,7 +336,7 @@ def test_iaea3d_128cube_golden(fuse3):
     for a, t in c["bc"]:
         s.set_bc(a, t)
     s.upload_xs(c["D"], c["SigR"], c["NSF"], c["Chi"], c["SigS"]); s.build()
-    s.set_option("cg_fuse3", fuse3)
+    s.set_option("cg_fuse3", fuse3); s.set_option("cg_fuse3_max_cells", 4 << 20)   # the fused launch is the default only up to 400 k cells
     r = gold["fixed"]
     s.set_tol(*r["tol"]); k, n = s.solve_keff()
     assert n == r["n_outer"] == 5

@@ -9,9 +9,10 @@ from helpers import TEST_TOL, degenerate_inputs, load_inputs, make_hip, make_ora
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
+PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
          ("resident-scans", dict(resident=1, resident_max_dofs=100000, resident_serial=0), 2),
-         ("resident-one-sided", dict(resident=1, resident_max_dofs=100000, resident_two_sided=0), 2)]   # one lane per line instead of a pair meeting in the middle   # RT0-P0 small enough for LDS: "resident" is the line-per-lane variant
+         ("resident-one-sided", dict(resident=1, resident_max_dofs=100000, resident_two_sided=0), 2),   # one lane per line instead of a pair meeting in the middle
+         ("classic-streaming", dict(resident=0, cg_fuse3=0, nt_min_cells=0), 0)]   # the big-mesh instantiations (non-temporal loads) forced onto small meshes   # RT0-P0 small enough for LDS: "resident" is the line-per-lane variant
 
 
 def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
@@ -44,6 +45,7 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
         assert rel_l2(r["J"].ravel(), o.J_dofs().ravel()) < 1e-7, name
+    assert res["classic-streaming"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-streaming"]["phi"], res["classic"]["phi"])   # same arithmetic, other load instructions
     for name in ("fuse3", "resident", "resident-scans", "resident-one-sided"):
         assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
         assert rel_l2(res[name]["phi"], res["classic"]["phi"]) < 1e-9
