@@ -268,6 +268,8 @@ def main():
     apply_bytes = (24.0 * Nl + 40.0 * sum(nJd[d] for d in range(dim))) * a.loopback_slabs + fused_bytes
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source, launches=dom["launches"], avg_ms=round(dom["avg_ms"], 4),
+                    event_sampling="HIP events bracket every 8th Schur apply of the timed steps (nf_set_option prof_every): an event record keeps "
+                                   "neighbouring launches from going out back to back, 8 records per apply cost 6 % of a CG iteration at 256^3",
                     alg_bytes_per_launch=dom["alg_bytes"], fused_cg_vector_bytes_in_x_pass=fused_bytes,
                     schur_apply=dict(avg_ms=round(cms / max(ca, 1), 4), alg_bytes=apply_bytes,
                                      achieved=round(apply_bytes / (cms / max(ca, 1) * 1e-3) / 1e9, 1),

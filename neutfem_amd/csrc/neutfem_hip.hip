@@ -112,7 +112,7 @@ struct nf_team {
     std::vector<double> hist_k, hist_dk, hist_dphi; std::vector<int> hist_cg;
     int has_valid_keff = 0; double last_keff = 1.0;
     // profiling
-    bool profile = false;
+    bool profile = false; long prof_tick = 0; int prof_every = 8;   // event-timed launches: every prof_every-th Schur apply of a profiled solve
     std::map<std::string, ProfSlot> prof;
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
@@ -960,15 +960,18 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
     const int dim = T->slabs[0]->dim;
     bool any_if = false; for (auto *S : T->slabs) any_if |= S->if_lo || S->if_hi;
     hipEvent_t a, b, ta = nullptr, tb = nullptr;
-    if (T->profile) prof_begin(T, 3, &ta, &tb);
+    // event-timed: every prof_every-th apply (an event record keeps the launches around it from being dispatched back to back:
+    // eight records per apply cost 36 us per CG iteration at 256^3, 6 % of the iteration they are meant to measure)
+    const bool prof = T->profile && (T->prof_tick++ % T->prof_every == 0);
+    if (prof) prof_begin(T, 3, &ta, &tb);
     if (any_if) {                                                 // partition method step 1 + interface exchange
-        if (T->profile) prof_begin(T, 4, &a, &b);
-        NFCHK(team_endpoint_phase(T, g, xs, ys, cg, T->profile ? b : nullptr));
+        if (prof) prof_begin(T, 4, &a, &b);
+        NFCHK(team_endpoint_phase(T, g, xs, ys, cg, prof ? b : nullptr));
     }
     for (int d = 0; d < dim; ++d) {
         const int last = d == dim - 1;
         if (d == 2 && any_if) HIPCHK(hipStreamWaitEvent(T->stream, T->ev_xchg, 0));
-        if (T->profile) prof_begin(T, d, &a, &b);
+        if (prof) prof_begin(T, d, &a, &b);
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
             const Geom G = make_geom(S);
@@ -985,9 +988,9 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
             }
             if (counts && last) (*counts)[i] = total;
         }
-        if (T->profile) (void)hipEventRecord(b, T->stream);
+        if (prof) (void)hipEventRecord(b, T->stream);
     }
-    if (T->profile) (void)hipEventRecord(tb, T->stream);
+    if (prof) (void)hipEventRecord(tb, T->stream);
     return NF_OK;
 }
 
@@ -1153,9 +1156,10 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 double *A = S0->d_p, *B = S0->d_p2;
                 double *pin = (index == 0 || (index & 1)) ? A : B, *pout = pin == A ? B : A;
                 hipEvent_t ta = nullptr, tb = nullptr;
-                if (T->profile) prof_begin(T, 3, &ta, &tb);
+                const bool prof = T->profile && (T->prof_tick++ % T->prof_every == 0);
+                if (prof) prof_begin(T, 3, &ta, &tb);
                 rc = launch_apply3(S0, g, f3, pin, pout, x[0], CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 });
-                if (T->profile) (void)hipEventRecord(tb, T->stream);
+                if (prof) (void)hipEventRecord(tb, T->stream);
                 hipLaunchKernelGGL(k_cg_rupdate3, dim3(gru), dim3(256), 0, T->stream, S0->d_r, (const double *)S0->d_q, (const double *)(S0->dim >= 2 ? S0->d_qy : nullptr),
                                    (const double *)(S0->dim == 3 ? S0->d_qz : nullptr), S0->nphi, T->d_cg, row1, CgLean{ T->d_cg, T->d_partials, f3.nblocks, index & 1, 0 });
                 continue;
@@ -2436,10 +2440,10 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
         xs.push_back(X->d_p); ys.push_back(X->d_q);
     }
     NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));   // warm-up
-    T->profile = true;
+    T->profile = true; const int every = T->prof_every; T->prof_every = 1;
     for (int i = 0; i < std::min(reps, 8); ++i) NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));
     HIPCHK(hipStreamSynchronize(T->stream));
-    prof_collect(T); T->profile = false;
+    prof_collect(T); T->profile = false; T->prof_every = every;
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     HIPCHK(hipEventRecord(a, T->stream));
     for (int i = 0; i < reps; ++i) NFCHK(team_schur_apply(T, g, xs, ys, false, nullptr, nullptr));
@@ -2503,6 +2507,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
+    else if (!strcmp(key, "prof_every")) { if (value < 1) return fail(NF_ERR_ARG, "prof_every must be >= 1"); T->prof_every = (int)value; }
     else if (!strcmp(key, "nt_loads")) T->opt_nt_loads = value != 0;
     else if (!strcmp(key, "nt_min_cells")) T->nt_min_cells = value;
     else if (!strcmp(key, "outer_dev")) T->opt_outer_dev = value != 0;
