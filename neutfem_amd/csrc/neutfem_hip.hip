@@ -879,7 +879,10 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const CgLean lz = (zmode == 1 && S->nloc == 1 && fz.p) ? S->lean_z1 : CgLean{ nullptr, nullptr, 0, 0, 0 };
     // undivided meshes beyond the caches (the classic path's sizes): the variant with streaming loads (SF doubles as that flag for !SLAB)
     const bool nt = zmode == 0 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;
-#define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+    const bool nts = zmode != 0 && zmode != 3 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;   // the same for the z passes of a slab
+#define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (SLABV && NBV == 0 && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (!SLABV && NBV == 0 && SEGV == 8 && nt) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, !SLABV && NBV == 0 && SEGV == 8>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); } while (0)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \

@@ -774,14 +774,14 @@ struct SlabArgs {
 // r + beta x, formed on the fly (see CgFuse).  Returns the thread's share of x.y.
 // SF (slab variants): the instantiation that can carry the fused CG update (r and x_sol of the cells in registers: 160 instead of
 // 128 VGPRs); the accumulation / emit passes use the one without
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, class Mid = NoMid>
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid>   // NTS: streaming loads in a slab variant
 __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                                                unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
                                                const SlabArgs &sa, const CgFuse &fz, bool fuse, bool fro, double f_alpha, double f_beta, bool acc,
                                                long long *stamp = nullptr, Mid mid = Mid())
 {
-    constexpr bool NT = !SLAB && SF;                             // undivided big meshes: streaming loads (ldg)
+    constexpr bool NT = SLAB ? NTS : SF;                         // big meshes: streaming loads (ldg); SF doubles as that flag on undivided meshes
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     double *__restrict__ y = ma.y[0];
     const int T = TX * NSEG;
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 
 // Slab variants keep r and x_sol of their cells in registers next to x, L, 1/d (loads first, see schur_s_tile): blocks of at most 512
 // threads, so that the register budget is 256 per thread (the host picks TX accordingly)
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false>
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false>
 __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4)) : 1) void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                           int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz, CgLean lean)
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
         const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
     }
-    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
+    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF, NTS>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
                                                             (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
     if (SLAB && sa.mode == 3) return;
     if (last && partials) {

@@ -80,6 +80,11 @@ def test_team_solve_keff_matches_undivided_and_oracle(planes):
     # same algorithm, only the summation order of the dot products differs: CG counts within 2 %
     hs, ht = s.history()["cg"][:min(ns, nt)], t.history()["cg"][:min(ns, nt)]
     assert np.abs(ht - hs).max() <= 0.02 * hs.max()
+    # the big-mesh instantiations of the passes (non-temporal loads; on by themselves beyond 8 M cells per slab): same arithmetic, same bits
+    for x in t.slabs:
+        x.set_option("nt_min_cells", 0)
+    t.reset_flux(); k2, n2 = t.solve_keff()
+    assert k2 == kt and n2 == nt and np.array_equal(t.get_phi_local().ravel(), phi_t)
     s.close(); t.close()
 
 
