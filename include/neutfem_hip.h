@@ -180,6 +180,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   "resident_two_sided" (default 1): lines of at least 4 cells are swept by two lanes that meet in the middle;
  *   "direct_max_dofs" (default 2048, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
  *   CG to 1e-14 stands in (nf_info "direct_standin_unconverged" counts group solves that did not get there);
+ *   "host_pub" (default 1): the host reads the CG scalars and the outer iteration's sums from a mapped host page that a one-thread
+ *   kernel fills (polled), not through a device-to-host copy and a stream drain;
  *   "prof_every" (default 8): a profiled solve (nf_keff_opts::profile) brackets every n-th Schur apply with events, not each one;
  *   "nt_loads" (default 1): on undivided RT0-P0 meshes of more than "nt_min_cells" cells (default 8 000 000: from there on the streams no longer live in the
  *   256 MB memory-side cache between launches) the direction passes read their streams with non-temporal loads;

@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -112,6 +113,7 @@ struct nf_team {
     std::vector<double> hist_k, hist_dk, hist_dphi; std::vector<int> hist_cg;
     int has_valid_keff = 0; double last_keff = 1.0;
     // profiling
+    HostPub *h_pub = nullptr, *d_pub = nullptr; unsigned long long pub_seq = 0; int opt_pub = 1;   // low-latency scalar readback (k_publish)
     bool profile = false; long prof_tick = 0; int prof_every = 8;   // event-timed launches: every prof_every-th Schur apply of a profiled solve
     std::map<std::string, ProfSlot> prof;
     struct Ev { hipEvent_t a, b; int slot; };
@@ -315,6 +317,7 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
     dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
+    if (T->h_pub) (void)hipHostFree(T->h_pub);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
     if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
     if (T->ev_xchg) (void)hipEventDestroy(T->ev_xchg);
@@ -661,6 +664,56 @@ int nf_build(nf_handle S)
     HIPCHK(hipStreamSynchronize(st));
     S->built = true; S->diag_valid = false; S->cmfd_init = false; S->cmfd_iface = false; S->dense_valid = false;   // src/NeutFEM.cpp:454-456
     S->team->linked_ready = false;
+    return NF_OK;
+}
+
+// Host wait for a stream with low wake-up latency: hipStreamSynchronize sleeps on an interrupt, which costs 20-30 us per wait -- as much
+// as two CG iterations of a 27 k-cell mesh, once per group solve and once per outer iteration.  Poll for a while first; long waits
+// (big meshes) fall through to the blocking call, which also reports errors.
+static hipError_t stream_wait(hipStream_t st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q != hipErrorNotReady) return q == hipSuccess ? hipSuccess : hipStreamSynchronize(st);
+        if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    return hipStreamSynchronize(st);
+}
+
+// Read the CG scalars and / or nout doubles of `out` back to the host: through the mapped page when available, else D2H copy + wait.
+static int readback(nf_team *T, const CgScalars *d_cg, CgScalars *h_cg, const double *d_out, double *h_out, int nout)
+{
+    hipStream_t st = T->stream;
+    if (T->opt_pub && !T->h_pub) {
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(HostPub), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { T->h_pub = (HostPub *)hp; T->d_pub = (HostPub *)dp; memset(hp, 0, sizeof(HostPub)); }
+            else (void)hipHostFree(hp);
+        }
+        if (!T->h_pub) { (void)hipGetLastError(); T->opt_pub = 0; }
+    }
+    if (T->opt_pub && T->h_pub) {
+        const unsigned long long seq = ++T->pub_seq;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, d_cg, d_out, nout, T->d_pub, seq);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (int i = 0;; ++i) {
+            if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (!seen) {                                              // long wait (big mesh) or an error: block, then look again
+            HIPCHK(hipStreamSynchronize(st));
+            if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) != seq) return fail(NF_ERR_HIP, "scalar readback: the device never published sequence %llu", seq);
+        }
+        if (h_cg) *h_cg = T->h_pub->cg;
+        for (int i = 0; i < nout; ++i) h_out[i] = T->h_pub->out[i];
+        return NF_OK;
+    }
+    if (h_cg) HIPCHK(hipMemcpyAsync(h_cg, d_cg, sizeof *h_cg, hipMemcpyDeviceToHost, st));
+    if (nout > 0) HIPCHK(hipMemcpyAsync(h_out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(stream_wait(st));
     return NF_OK;
 }
 
@@ -1205,9 +1258,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         // lean: the stop tests of the batch's last iteration have not been evaluated yet (the next x pass would do it)
         if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 });
         if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 1, -1, launched & 1, 0 });
-        if (hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream) != hipSuccess || hipStreamSynchronize(T->stream) != hipSuccess) {
-            rc = fail(NF_ERR_HIP, "CG: reading the device scalars failed"); break;
-        }
+        if (readback(T, T->d_cg, &sc, nullptr, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
         if (sc.done) break;
         // after the first (predicted) batch grow geometrically: an iteration launched past convergence is five early-exit
         // kernels (~10 us), a host check is a D2H copy + stream drain (~50 us)
@@ -1921,7 +1972,7 @@ static int solve_keff_diag_device(nf_team *T, const nf_keff_opts *o, double keff
         }
         queued += nb;
         HIPCHK(hipMemcpyAsync(&hs, T->d_ost, sizeof hs, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(st));
         if (hs.done || hs.done_next) break;
     }
     HIPCHK(hipGetLastError());
@@ -2085,7 +2136,7 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     HIPCHK(hipGetLastError());
     ResidentOut ro;
     HIPCHK(hipMemcpyAsync(&ro, T->d_rout, sizeof ro, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(st));
     const int n = ro.n_outer;
     T->hist_k.resize(n); T->hist_dk.resize(n); T->hist_dphi.resize(n); T->hist_cg.resize((size_t)n * ng);
     if (n > 0) {
@@ -2206,8 +2257,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             hipLaunchKernelGGL(k_outer_reduce, dim3(gT[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_raw, S->d_phi, S->nphi * ng, T->d_partials + i * T->slab_cap, T->partial_stride);
         }
         NFCHK(team_finalize(T, FIN_SUM, gT, 3, T->d_out + 1, 0.0, 0));
-        HIPCHK(hipMemcpyAsync(hout, T->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, T->stream));
-        HIPCHK(hipStreamSynchronize(T->stream));
+        NFCHK(readback(T, nullptr, nullptr, T->d_out, hout, 4));
         const double prod_old = hout[0], prod_new = hout[1], nsq = hout[2], dsq = hout[3];
         const double keff_new = keff * (prod_new / prod_old);
         const double dk = std::fabs(keff_new - keff);
@@ -2510,6 +2560,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
+    else if (!strcmp(key, "host_pub")) T->opt_pub = value != 0;
     else if (!strcmp(key, "prof_every")) { if (value < 1) return fail(NF_ERR_ARG, "prof_every must be >= 1"); T->prof_every = (int)value; }
     else if (!strcmp(key, "nt_loads")) T->opt_nt_loads = value != 0;
     else if (!strcmp(key, "nt_min_cells")) T->nt_min_cells = value;

@@ -33,6 +33,19 @@ struct CgScalars {
     double rr2[2]; int its2[2];
 };
 
+// Low-latency readback of a few scalars: a one-thread kernel copies them into host memory that the device can write (mapped, coherent)
+// and then stores a sequence number with system-scope release; the host polls the sequence number.  Replaces a 100-byte D2H copy
+// through the copy engine + stream drain, which costs ~30 us of idle GPU per check (once per group solve and per outer iteration).
+struct HostPub { CgScalars cg; double out[8]; unsigned long long seq; };
+__global__ void k_publish(const CgScalars *__restrict__ cg, const double *__restrict__ out, int nout, HostPub *hp, unsigned long long seq)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (cg) hp->cg = *cg;
+    for (int i = 0; i < nout && i < 8; ++i) hp->out[i] = out[i];
+    __threadfence_system();
+    __hip_atomic_store(&hp->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Sum over the 64 lanes of a wavefront, result in every lane.  Data-parallel-primitive moves (row_shr 1/2/4/8 inside each row of
 // 16 lanes, then row_bcast 15 and 31 across rows) instead of ds_bpermute shuffles: six dependent steps of a few cycles each where
 // the LDS crossbar costs ~100 cycles per step -- the reductions sit on the critical path of every latency-bound kernel here.
