@@ -682,9 +682,8 @@ static hipError_t stream_wait(hipStream_t st)
 }
 
 // Read the CG scalars and / or nout doubles of `out` back to the host: through the mapped page when available, else D2H copy + wait.
-static int readback(nf_team *T, const CgScalars *d_cg, CgScalars *h_cg, const double *d_out, double *h_out, int nout)
+static bool pub_ready(nf_team *T)                                 // the mapped page exists (created on first use)
 {
-    hipStream_t st = T->stream;
     if (T->opt_pub && !T->h_pub) {
         void *hp = nullptr;
         if (hipHostMalloc(&hp, sizeof(HostPub), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -694,22 +693,31 @@ static int readback(nf_team *T, const CgScalars *d_cg, CgScalars *h_cg, const do
         }
         if (!T->h_pub) { (void)hipGetLastError(); T->opt_pub = 0; }
     }
-    if (T->opt_pub && T->h_pub) {
+    return T->opt_pub && T->h_pub;
+}
+static int pub_wait(nf_team *T, unsigned long long seq, CgScalars *h_cg, double *h_out, int nout)   // a kernel of the stream publishes `seq`
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (int i = 0;; ++i) {
+        if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+        if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    if (!seen) {                                                  // long wait (big mesh) or an error: block, then look again
+        HIPCHK(hipStreamSynchronize(T->stream));
+        if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) != seq) return fail(NF_ERR_HIP, "scalar readback: the device never published sequence %llu", seq);
+    }
+    if (h_cg) *h_cg = T->h_pub->cg;
+    for (int i = 0; i < nout; ++i) h_out[i] = T->h_pub->out[i];
+    return NF_OK;
+}
+static int readback(nf_team *T, const CgScalars *d_cg, CgScalars *h_cg, const double *d_out, double *h_out, int nout)
+{
+    hipStream_t st = T->stream;
+    if (pub_ready(T)) {
         const unsigned long long seq = ++T->pub_seq;
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, d_cg, d_out, nout, T->d_pub, seq);
-        const auto t0 = std::chrono::steady_clock::now();
-        bool seen = false;
-        for (int i = 0;; ++i) {
-            if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-            if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-        }
-        if (!seen) {                                              // long wait (big mesh) or an error: block, then look again
-            HIPCHK(hipStreamSynchronize(st));
-            if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) != seq) return fail(NF_ERR_HIP, "scalar readback: the device never published sequence %llu", seq);
-        }
-        if (h_cg) *h_cg = T->h_pub->cg;
-        for (int i = 0; i < nout; ++i) h_out[i] = T->h_pub->out[i];
-        return NF_OK;
+        return pub_wait(T, seq, h_cg, h_out, nout);
     }
     if (h_cg) HIPCHK(hipMemcpyAsync(h_cg, d_cg, sizeof *h_cg, hipMemcpyDeviceToHost, st));
     if (nout > 0) HIPCHK(hipMemcpyAsync(h_out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1160,8 +1168,9 @@ static int launch_apply3(nf_solver *S, int g, const Fuse3Plan &P, const double *
 
 // ---- CG (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636) -----------------------------
 // rhs / x: per-slab pointers
+// inited: k_group_rhs has already written x = 0, r = p = rhs and the |rhs|^2 partials (one launch less per group solve)
 static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, const std::vector<double *> &x, double tol, int maxit,
-                    int *its_out, double *res_out)
+                    int *its_out, double *res_out, bool inited = false)
 {
     const int ns = (int)T->slabs.size();
     std::vector<int> gcnt(ns), acnt(ns);
@@ -1169,7 +1178,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     for (int i = 0; i < ns; ++i) {
         nf_solver *S = T->slabs[i];
         gcnt[i] = grid_for(S->nphi); ps[i] = S->d_p; qs[i] = S->d_q;
-        hipLaunchKernelGGL(k_cg_init, dim3(gcnt[i]), dim3(256), 0, T->stream, rhs[i], x[i], S->d_r, S->d_p, S->nphi, T->d_partials + i * T->slab_cap);
+        if (!inited) hipLaunchKernelGGL(k_cg_init, dim3(gcnt[i]), dim3(256), 0, T->stream, rhs[i], x[i], S->d_r, S->d_p, S->nphi, T->d_partials + i * T->slab_cap);
     }
     NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
     CgScalars sc; memset(&sc, 0, sizeof sc);
@@ -1256,9 +1265,15 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         if (rc != NF_OK) break;
         launched += nb;
         // lean: the stop tests of the batch's last iteration have not been evaluated yet (the next x pass would do it)
-        if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 });
-        if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 1, -1, launched & 1, 0 });
-        if (readback(T, T->d_cg, &sc, nullptr, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
+        if (lean && pub_ready(T)) {                               // the kernel that evaluates the stop tests hands the scalars to the host itself
+            const unsigned long long seq = ++T->pub_seq;
+            hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, T->d_pub, seq);
+            if (pub_wait(T, seq, &sc, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
+        } else {
+            if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
+            if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 1, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
+            if (readback(T, T->d_cg, &sc, nullptr, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
+        }
         if (sc.done) break;
         // after the first (predicted) batch grow geometrically: an iteration launched past convergence is five early-exit
         // kernels (~10 us), a host check is a D2H copy + stream drain (~50 us)
@@ -2237,15 +2252,19 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
                 nf_solver *S = T->slabs[i]; const long N = S->N, NP = S->nphi;
                 for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[g * ng + gp] : nullptr;
                 double *dst = use_diag ? S->d_raw + g * NP : S->d_rhs;
+                // CG path: the start of the solve (x = 0, r = p = rhs, |rhs|^2 partials) rides in the same launch (cg_solve(..., inited))
+                const bool cgi = !use_diag && !dense;
                 hipLaunchKernelGGL(k_group_rhs, dim3(gN[i]), dim3(256), 0, T->stream, sa, g, S->d_Chi + g * N, S->d_tf, 1.0 / keff, S->d_raw, S->d_phi,
-                                   use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, NP, N);
+                                   use_diag ? S->d_Sinv + g * N : (const double *)nullptr, dst, NP, N,
+                                   cgi ? S->d_raw + g * NP : (double *)nullptr, cgi ? S->d_r : (double *)nullptr, cgi ? S->d_p : (double *)nullptr,
+                                   cgi ? T->d_partials + i * T->slab_cap : (double *)nullptr);
                 rhs[i] = S->d_rhs; sol[i] = S->d_raw + g * NP;
             }
             int its = 0; double res = 0.0;
             if (use_diag) { }
             else if (dense) { dense_solve(T, g, rhs[0], sol[0]); its = 1; }          // last_iterations_ = 1 (src/solvers.cpp:447)
             else {
-                NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, &res));
+                NFCHK(cg_solve(T, g, rhs, sol, cg_tol, cg_max, &its, &res, true));
                 if (direct && !(res <= 1e-14)) ++T->standin_unconverged;
             }
             T->hist_cg.push_back(its); T->last_cg_total += its;

@@ -256,12 +256,19 @@ __device__ __forceinline__ bool lean_rr_step(const CgLean &lean, bool writer, do
 }
 // what a direction pass does between issuing its loads and using them (nothing, by default)
 struct NoMid { __device__ __forceinline__ bool operator()(double &, double &) const { return false; } };
-__global__ __launch_bounds__(256) void k_cg_lean_rr(CgLean lean)
+// hp: publish the scalars to the host right away (end of a batch of iterations: the host is polling, see HostPub)
+__global__ __launch_bounds__(256) void k_cg_lean_rr(CgLean lean, HostPub *hp, unsigned long long seq)
 {
     __shared__ double sred[4];
-    if (lean.st->done) return;
-    double beta;
-    (void)lean_rr_step(lean, threadIdx.x == 0, sred, &beta);
+    if (!lean.st->done) {
+        double beta;
+        (void)lean_rr_step(lean, threadIdx.x == 0, sred, &beta);
+    }
+    if (hp && threadIdx.x == 0) {                                // the same thread wrote the scalars above
+        hp->cg = *lean.st;
+        __threadfence_system();
+        __hip_atomic_store(&hp->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1374,11 +1381,17 @@ struct ScatterArgs { const double *M[64]; int ng; };
 // iterate, gp > g from the old one) (:1716-1726).  If sinv != NULL the diagonal solve phi = S_inv * rhs is
 // fused (:607-613) and written to out, otherwise out = rhs.
 // n = DOFs per group (SoA [p][e]), ncell = cells: chi is per cell; for P>=1 elements with |chi/k| < 1e-14 are skipped (:1551).
+// With r0 != nullptr the CG start of src/solvers.cpp:583-592 rides along (x = 0, r = p = rhs, block partials of |rhs|^2: what k_cg_init
+// does), one launch less per group solve.
 __global__ __launch_bounds__(256) void k_group_rhs(ScatterArgs sa, int g, const double *__restrict__ chi,
                                                    const double *__restrict__ tf, double inv_k,
                                                    const double *__restrict__ phi_new, const double *__restrict__ phi_old,
-                                                   const double *__restrict__ sinv, double *__restrict__ out, long n, long ncell)
+                                                   const double *__restrict__ sinv, double *__restrict__ out, long n, long ncell,
+                                                   double *__restrict__ x0 = nullptr, double *__restrict__ r0 = nullptr, double *__restrict__ p0 = nullptr,
+                                                   double *__restrict__ partials = nullptr)
 {
+    __shared__ double sred[4];
+    double s2 = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
         double v;
         if (n == ncell) v = inv_k * (chi[i] * tf[i]);
@@ -1389,6 +1402,11 @@ __global__ __launch_bounds__(256) void k_group_rhs(ScatterArgs sa, int g, const 
             v += sa.M[gp][i] * ph[gp * n + i];
         }
         out[i] = sinv ? sinv[i] * v : v;
+        if (r0) { x0[i] = 0.0; r0[i] = v; p0[i] = v; s2 += v * v; }
+    }
+    if (r0) {
+        s2 = block_sum(s2, sred);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s2;
     }
 }
 // partial sums of prod_new, ||phi||^2, ||phi - phi_old||^2 over all groups       (:1766-1779)
