@@ -875,10 +875,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     for (int i = 0; i <= SEG; ++i) {
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
-        xv[i] = ok ? ldg<NT>(x + a) : 0.0;
+        xv[i] = ok ? (i == SEG ? ldg<false>(x + a) : ldg<NT>(x + a)) : 0.0;   // the overlap cell is the next segment's first: keep that line for it
         if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : ldg<NT>(x + a + roff)) : 0.0;
         if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
-        Lv[i] = ok ? ldg<NT>(L + a) : 0.0;
+        Lv[i] = ok ? (i == SEG ? ldg<false>(L + a) : ldg<NT>(L + a)) : 0.0;
         if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
         if (NB > 0) {
             v1a[i] = ok ? ma.x[1][a] : 0.0;
