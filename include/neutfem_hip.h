@@ -165,7 +165,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
 /* tuning knobs (no reference counterpart):
  *   "s_tx" (0 auto, 8, 16, 32, 64) columns per block and "s_seg" (0 auto, 4, 8, 16, 32) cells per register segment of the y/z line
  *   kernels; "s_wsmin" segments per line from which whole wavefronts scan the segment summaries (default 64);
- *   "xcd" (default 0) gives each XCD one contiguous range of y/z tiles (measured: no gain);
+ *   "xcd" gives each XCD one contiguous range of tiles: bit 0 the y passes, bit 1 the z passes; default -1 = the y passes of meshes
+ *   beyond "nt_min_cells" (256^3: y pass 133 -> 123 us; the z passes lose with it, smaller meshes see nothing);
  *   "cg_batch" CG iterations launched between host checks of the device-side stop flag (0 = automatic);
  *   "cg_fuse" (default 1) folds x += alpha p, p = r + beta p into the next pass that reads p (bit-identical iterates);
  *   "cg_lean" (default 1) lets the consumer of a reduction derive the CG scalars itself: no finalize launches on undivided meshes of at

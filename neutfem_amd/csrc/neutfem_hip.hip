@@ -121,7 +121,7 @@ struct nf_team {
     int cg_batch = 0;
     // 192^3 (7.1 M cells): 229 -> 233 us per CG iteration with them, 224^3 (11.2 M): 389 -> 356, 256^3: 599 -> 550
     int opt_nt_loads = 1; long nt_min_cells = 8000000;   // streaming (non-temporal) loads in the y / z passes of undivided meshes larger than this
-    int opt_fuse = 1, opt_xcd = 0, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID, opt_sepfold = 1;
+    int opt_fuse = 1, opt_xcd = -1, opt_outer_dev = 1, opt_lean = 1, opt_lean_grid = RED_GRID, opt_sepfold = 1;
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
@@ -879,7 +879,8 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const ModeTab mt = mode_tab(S, 0);
     const dim3 gr(grid, (unsigned)mt.n);                          // all transverse modes in one launch
     const bool nt = NB == 0 && vec && S->team->opt_nt_loads && N > S->team->nt_min_cells;   // streaming loads beyond the caches (per slab on teams)
-    if (nt) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB, NB == 0>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
+    if (nt) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB, NB == 0>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2,
+                               first | ((S->team->opt_xcd >= 0 && (S->team->opt_xcd & 4)) ? 2 : 0), last, partials, cg, fz, S->lean);
     else if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
     else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
 }
@@ -934,7 +935,11 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
-    sa.xcd = T->opt_xcd; sa.wsmin = T->opt_wsmin;
+    // XCD-contiguous tile order (k_schur_s): bit 0 = y passes, bit 1 = z passes; -1 (default) = the y passes of meshes in the streaming
+    // regime -- the 8 x tiles of a row set then run on one XCD back to back (256^3: y 133 -> 123 us, 501 -> 493 us per CG iteration;
+    // z passes lose 10 us with it; neutral to -0.5 % at 96^3 ... 192^3)
+    sa.xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : (d == 1 && T->opt_nt_loads && S->N > T->nt_min_cells);
+    sa.wsmin = T->opt_wsmin;
     const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 16) * sizeof(double);
     const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
     const CgLean lz = (zmode == 1 && S->nloc == 1 && fz.p) ? S->lean_z1 : CgLean{ nullptr, nullptr, 0, 0, 0 };
@@ -2578,7 +2583,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
-    else if (!strcmp(key, "xcd")) T->opt_xcd = value != 0;
+    else if (!strcmp(key, "xcd")) T->opt_xcd = value < 0 ? -1 : (int)(value & 7);
     else if (!strcmp(key, "host_pub")) T->opt_pub = value != 0;
     else if (!strcmp(key, "prof_every")) { if (value < 1) return fail(NF_ERR_ARG, "prof_every must be >= 1"); T->prof_every = (int)value; }
     else if (!strcmp(key, "nt_loads")) T->opt_nt_loads = value != 0;

@@ -755,12 +755,15 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
         if (lean_on) stopped = lean_rr_step(lean, pre, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, sred, &fb);
         return stopped;
     };
-    const double dot = schur_x_task<K, NCH, VEC, NB, decltype(mid), false, NT>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first, (long)blockIdx.x * 4 + (threadIdx.x >> 6),
+    // bit 1 of `first`: XCD-contiguous block order (consecutive workgroups go round-robin to the 8 XCDs; each then walks one eighth of the lines)
+    unsigned bx = blockIdx.x;
+    if ((first & 2) && gridDim.x % 8 == 0) bx = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    const double dot = schur_x_task<K, NCH, VEC, NB, decltype(mid), false, NT>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first & 1, (long)bx * 4 + (threadIdx.x >> 6),
                                                                                threadIdx.x & 63, true, fuse, alpha0, beta0, fz, mid);
     if (stopped) return;                                         // decided inside, the same in every block: nothing to reduce
     if (last && partials) {
         const double s = block_sum(dot, sred);
-        if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
+        if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + bx] = s;   // by position: the sum order does not depend on the block order
     }
 }
 
