@@ -32,14 +32,16 @@ def iaea3d_resampled(n, nz=None, z_range=None):
                 name=f"IAEA-3D resampled {n}x{n}x{nz} RT0-P0 2g")
 
 
-def synthetic_checkerboard(n, ng=8, z_range=None):
+def synthetic_checkerboard(n, ng=8, z_range=None, nxy=None):
     """SURVEY.md 8d C5 (h = 1 cm, material id ((ix>>4)+(iy>>4)+(iz>>4))&1, 0 = fuel, 1 = moderator).
-    z_range = (k0, k1): only those z-planes of the XS arrays (slab-decomposed runs); z_breaks stay global."""
+    z_range = (k0, k1): only those z-planes of the XS arrays (slab-decomposed runs); z_breaks stay global.
+    nxy: cells along x and y (default n) -- a column of the same pattern with full-length z lines (parity tests, bench self-check)."""
+    nxy = nxy or n
     brk = np.linspace(0.0, float(n), n + 1)
     i = np.arange(n) >> 4
     k0, k1 = z_range if z_range is not None else (0, n)
-    mod = ((i[k0:k1, None, None] + i[None, :, None] + i[None, None, :]) & 1).astype(bool)
-    shp = (k1 - k0, n, n)
+    mod = ((i[k0:k1, None, None] + i[None, :nxy, None] + i[None, None, :nxy]) & 1).astype(bool)
+    shp = (k1 - k0, nxy, nxy)
     D = np.empty((ng,) + shp); SigR = np.empty((ng,) + shp); NSF = np.zeros((ng,) + shp); Chi = np.zeros((ng,) + shp)
     SigS = np.zeros((ng, ng) + shp)
     chi = [0.60, 0.30, 0.08, 0.02] + [0.0] * 60
@@ -54,5 +56,6 @@ def synthetic_checkerboard(n, ng=8, z_range=None):
         SigR[g] = siga + out
         NSF[g] = np.where(mod, 0.0, 0.004 * 1.7 ** g)
         Chi[g] = np.where(mod, 0.0, chi[g])
-    return dict(x_breaks=brk, y_breaks=brk.copy(), z_breaks=brk.copy(), D=D, SigR=SigR, NSF=NSF, Chi=Chi, SigS=SigS,
-                bc=DIRICHLET_3D, ng=ng, coarse_factors=[2, 2, 2], name=f"synthetic checkerboard {n}^3 RT0-P0 {ng}g")
+    return dict(x_breaks=brk[:nxy + 1].copy(), y_breaks=brk[:nxy + 1].copy(), z_breaks=brk.copy(), D=D, SigR=SigR, NSF=NSF, Chi=Chi, SigS=SigS,
+                bc=DIRICHLET_3D, ng=ng, coarse_factors=[2, 2, 2],
+                name=f"synthetic checkerboard {n}^3 RT0-P0 {ng}g" if nxy == n else f"synthetic checkerboard {nxy}x{nxy}x{n} RT0-P0 {ng}g")

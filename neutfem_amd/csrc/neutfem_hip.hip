@@ -125,6 +125,8 @@ struct nf_team {
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
+    int opt_s_long = -1, s_long_min = 256;                // chunked long-line pass (k_schur_c): -1 auto (lines longer than s_long_min), 0 off, 1 always
+    size_t lds_limit = 160 * 1024;                        // dynamic LDS a block may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock at team creation)
     // fused-direction CG (two launches per iteration) up to this many cells.  Measured crossover against the four-launch lean path after
     // the round-2 latency work: 64^3 19.1 vs 27.2 us per CG iteration, 80^3 39.1 vs 34.5, 128^3 77.7 vs 70.9, 160^3 221 vs 150
     int opt_fuse3 = 1; long fuse3_max_cells = 400000;
@@ -371,6 +373,13 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     S->nlines[0] = (long)S->ny * S->nz; S->nlines[1] = (long)S->nx * S->nz; S->nlines[2] = (long)S->nx * S->ny;
     nf_team *T = new nf_team();
     T->device = device; T->slabs.push_back(S); S->team = T; S->slab_index = 0;
+    {   // dynamic LDS a workgroup may ask for on this device (gfx950: 160 KiB); the LDS-resident paths plan against it and step aside when it is smaller
+        int a = 0, b = 0;
+        if (hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) a = 0;
+        if (hipDeviceGetAttribute(&b, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess) b = 0;
+        (void)hipGetLastError();
+        T->lds_limit = (size_t)std::max(std::max(a, b), 64 * 1024);
+    }
     const char *cb = getenv("NEUTFEM_CG_BATCH"); T->cg_batch = cb ? atoi(cb) : 0;
     *out = S;
     int rc = NF_OK;
@@ -919,6 +928,28 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const long nxy = (long)S->nx * S->ny;
     const long sl = d == 1 ? S->nx : nxy, ostride = d == 1 ? nxy : S->nx;
     const int nouter = d == 1 ? S->nz : S->ny;
+    // long plain lines of RT0-P0 meshes: two chunks per block, twice the tile width (k_schur_c).  s_long: -1 = from 257 cells per line
+    // (where k_schur_s would drop below 32 columns), 0 = never, 1 = whenever the shape allows (tests)
+    if (S->nb == 0 && zmode == 0 && (T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min))) {
+        const int NS = (n + 15) / 16;                                // segments of 8 cells per chunk, two chunks
+        int TXc = T->opt_s_tx ? T->opt_s_tx : 64;
+        while (TXc > 8 && TXc * NS > 1024) TXc >>= 1;
+        while (TXc > 8 && TXc / 2 >= S->nx) TXc >>= 1;
+        const size_t ldsc = (size_t)(3 * TXc * NS + 2 * TXc + 16 + 2 * 8 * NS * TXc) * sizeof(double);
+        if (TXc * NS <= 1024 && ldsc <= T->lds_limit) {
+            dim3 grid((unsigned)((S->nx + TXc - 1) / TXc), (unsigned)nouter), block((unsigned)((TXc * NS + 63) / 64 * 64));
+            if (nparts) *nparts = (int)(grid.x * grid.y);
+            const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
+            const bool nt = T->opt_nt_loads && S->N > T->nt_min_cells;
+            const int xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : (d == 1 && nt);
+#define NF_C(DIRV, NTV) do { static bool attr_set = false; \
+            if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_schur_c<DIRV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T->lds_limit)); attr_set = true; } \
+            hipLaunchKernelGGL((k_schur_c<DIRV, NTV>), grid, block, ldsc, T->stream, ma.x[0], ma.y[0], ma.Ta, L, DR, D0, n, sl, ostride, S->nx, TXc, NS, last, partials, cg, xcd); } while (0)
+            if (d == 1) { if (nt) NF_C(1, true); else NF_C(1, false); } else { if (nt) NF_C(2, true); else NF_C(2, false); }
+#undef NF_C
+            return NF_OK;
+        }
+    }
     // 8-cell segments up to 1024 cells per line (16 / 32 cells spill to scratch: 1.4x slower even though TX drops to 8 at 1024)
     int SEG = T->opt_s_seg ? T->opt_s_seg : (S->nb > 0 ? (n <= 256 ? 4 : 8) : (n <= 1024 ? 8 : (n <= 2048 ? 16 : 32)));
     int NSEG = (n + SEG - 1) / SEG;
@@ -2037,7 +2068,7 @@ static bool resident_plan(const nf_solver *S, ResidentArgs *A)
 static bool resident_serial_fits(const nf_team *T, const nf_solver *S)
 {
     if (!T->opt_resident_serial || !T->opt_resident_lds) return false;
-    const long cap = 160 * 1024 / 8 - 32;
+    const long cap = (long)T->lds_limit / 8 - 32;
     const long Np = (long)(S->nx | 1) * S->ny * S->nz;
     long lines = 0; for (int d = 0; d < S->dim; ++d) lines += (S->nlines[d] + 1) & ~1L;
     if (S->nb == 0) { const long pitch = Np <= 1536 ? 1536 : 2560; return Np <= pitch && 64 + 16 + (1 + 3L * S->dim) * pitch + 3 * lines <= cap; }
@@ -2077,7 +2108,7 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     A.Cd0 = S->d_Cd; A.lds_mask = 0;
     // RT0-P0: the line-per-lane variant when everything its sweeps touch fits in LDS (p, the contribution of every direction, the
     // factors and first pivots); r, x_sol and the C diagonal follow as far as there is room
-    const long cap = 160 * 1024 / 8 - 32;
+    const long cap = (long)T->lds_limit / 8 - 32;
     bool serial = false;
     if (S->nb == 0 && T->opt_resident_serial && T->opt_resident_lds && S->nphi <= T->resident_serial_max_dofs) {
         const long Np = (long)(S->nx | 1) * S->ny * S->nz;     // rows padded to an odd length (bank-conflict-free x lines)
@@ -2581,6 +2612,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
+    else if (!strcmp(key, "s_long")) T->opt_s_long = value < 0 ? -1 : (value > 0 ? 1 : 0);
+    else if (!strcmp(key, "s_long_min")) T->s_long_min = (int)std::max(1L, std::min(1000000L, value));
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;
     else if (!strcmp(key, "xcd")) T->opt_xcd = value < 0 ? -1 : (int)(value & 7);

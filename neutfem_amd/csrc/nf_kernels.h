@@ -813,7 +813,9 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     // and hand every thread its incoming value through LDS: one more barrier per sweep, which only pays for the longest loops
     // (measured on one box, s_wsmin: 512-cell lines 77 -> 72 us, but 256-cell lines 134 -> 141 us, 384-cell 513 -> 540 us, 128-cell
     // 59 -> 66 us).  Needs full, aligned wavefronts.
-    const bool wscan = NSEG >= (sa.wsmin > 0 ? sa.wsmin : 64) && (T & 63) == 0;
+    // (one wavefront spans a column's summaries: at most 64 segments -- a wider scan would need shuffles across wavefronts; longer
+    // lines keep the serial loops)
+    const bool wscan = NSEG >= (sa.wsmin > 0 ? sa.wsmin : 64) && NSEG <= 64 && (T & 63) == 0;
     const int NSP = wscan ? (NSEG | 1) : NSEG;                   // odd row length: conflict-free column-major rows
     const int TP = wscan ? TX * NSP : T;
     double *sA = sm, *sB = sm + TP, *sA2 = sm + 2 * TP, *sB2 = sm + 3 * TP, *sZ0 = sm + 4 * TP;
@@ -878,10 +880,11 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     for (int i = 0; i <= SEG; ++i) {
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
-        xv[i] = ok ? (i == SEG ? ldg<false>(x + a) : ldg<NT>(x + a)) : 0.0;   // the overlap cell is the next segment's first: keep that line for it
+        // the overlap cell (i == SEG) is the next segment's first: keep that line for it (see k_schur_c on why this is not a ternary on i)
+        if (i < SEG) xv[i] = ok ? ldg<NT>(x + a) : 0.0; else xv[i] = ok ? x[a] : 0.0;
         if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : ldg<NT>(x + a + roff)) : 0.0;
         if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
-        Lv[i] = ok ? (i == SEG ? ldg<false>(L + a) : ldg<NT>(L + a)) : 0.0;
+        if (i < SEG) Lv[i] = ok ? ldg<NT>(L + a) : 0.0; else Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
         if (NB > 0) {
             v1a[i] = ok ? ma.x[1][a] : 0.0;
@@ -1171,6 +1174,126 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
         double *sred = sm + 4 * TX * (NSEG + 1) + TX;
         const double s = block_sum(dot, sred);
         if (threadIdx.x == 0) partials[((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Long y / z lines (RT0-P0, plain lines: no slab interfaces).  k_schur_s holds a whole line in the registers of one block, so at
+// 512 cells per line a block is only 16 columns wide (128-byte row pieces) and at 1024 cells 8 (64 bytes).  Here the line is cut
+// into TWO chunks of CH = 8 NS cells and the block is twice as wide for the same number of threads:
+//   forward sweep of chunk 0 (its face values w and its factors L are parked in LDS: 2 x 64 KB for 1024 threads), forward and
+//   backward sweep of chunk 1 out of registers (exactly k_schur_s's body), backward sweep of chunk 0 out of LDS.
+// A chunk boundary is a segment boundary like any other -- the same affine-map summaries, composed serially per thread; the z
+// (u) value that crosses it is handed over through sC.  Every global array is still read once and written once per pass; only the
+// p.q share of chunk 0 (last pass of an apply inside CG) re-reads x, which the parked arrays leave no LDS for.
+// LDS (doubles): sA, sB [NS TX] (forward and backward summaries in turn), sC, sL1 [TX], 16 of reduction scratch, pW, pL [CH TX], pZ [NS TX].
+// Per cell the same expressions as k_schur_s (the value crossing the chunk boundary is the swept one, not a composed summary:
+// the two kernels agree to rounding, not bitwise).
+template <int DIR, bool NT>
+__global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ x, double *__restrict__ y, double Ta,
+                                                     const double *__restrict__ L, const double *__restrict__ DR, const double *__restrict__ D0,
+                                                     int n, long sl, long outer_stride, int nx, int TX, int NS, int last,
+                                                     double *__restrict__ partials, const CgScalars *__restrict__ cg, int xcd)
+{
+    extern __shared__ double sm[];
+    if (cg && cg->done) return;
+    constexpr int SEG = 8;
+    const int T = TX * NS, CH = NS * SEG;
+    double *sA = sm, *sB = sm + T, *sC = sm + 2 * T, *sL1 = sC + TX, *sred = sL1 + TX, *pW = sred + 16, *pL = pW + (long)CH * TX, *pZ = pL + (long)CH * TX;
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (xcd) {                                                   // XCD-contiguous tile order, as in k_schur_s
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
+    }
+    const int tid = (int)threadIdx.x;
+    const bool act = tid < T;
+    const int ixl = act ? tid % TX : 0, seg = act ? tid / TX : 0, si = seg * TX + ixl;
+    const int ix = (int)bx * TX + ixl;
+    const bool valid = act && ix < nx;
+    const long base = (long)by * outer_stride + ix, lineid = (long)by * nx + ix;
+    const bool need_dot = last && partials;
+    double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], w[SEG], yo[SEG];
+    double zin = 0.0, dinv_s = 0.0, zc = 0.0;
+    // ---- forward sweeps, chunk 0 then chunk 1
+    for (int ch = 0; ch < 2; ++ch) {
+        const int c0 = ch * CH + seg * SEG;
+#pragma unroll
+        for (int i = 0; i <= SEG; ++i) {                         // loads only (see schur_s_tile)
+            const int c = c0 + i; const bool ok = valid && c < n;
+            const long a = base + (long)c * sl;
+            // the overlap cell (i == SEG) is the next segment's first: a plain load keeps that line for it.  Two statements, not a
+            // ternary on i: before the loop is unrolled a ternary is one load in each arm of a branch, which the optimiser merges
+            // into a single load WITHOUT the hint (that is what round 2's kernels ran: every load of x was a plain one)
+            if (i < SEG) { xv[i] = ok ? ldg<NT>(x + a) : 0.0; Lv[i] = ok ? ldg<NT>(L + a) : 0.0; Rv[i] = ok ? ldg<NT>(DR + a) : 0.0; }
+            else { xv[i] = ok ? x[a] : 0.0; Lv[i] = ok ? L[a] : 0.0; }
+        }
+        double ds = 0.0;
+        if (valid && c0 < n) ds = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
+        if (ch) __syncthreads();                                 // chunk 0's summaries and carry have been consumed
+        double P = 1.0, lz = 0.0;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) { const double ti = xv[i] - xv[i + 1]; lz = ti - Lv[i] * lz; P = -Lv[i] * P; }
+        if (act) { sA[si] = P; sB[si] = lz; }
+        if (act && ch == 0 && seg == 0) sC[ixl] = -xv[0];        // z entering the line (Dirichlet / natural end: no cell below)
+        if (act && ch == 1 && seg == NS - 1) sC[ixl] = zc;       // z leaving chunk 0
+        if (act && ch == 1 && seg == 0) sL1[ixl] = Lv[0];        // the factor just above chunk 0 (its last segment's overlap cell)
+        __syncthreads();
+        double z = sC[ixl];
+        for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
+        zin = z; dinv_s = ds;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) { const double ti = xv[i] - xv[i + 1]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; }
+        zc = z;
+        if (ch == 0) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < SEG; ++i) { pW[(seg * SEG + i) * TX + ixl] = w[i]; pL[(seg * SEG + i) * TX + ixl] = Lv[i]; }
+                pZ[si] = zin;
+            }
+        }
+    }
+    // ---- backward sweeps and output, chunk 1 (still in registers) then chunk 0 (from LDS)
+    double dot = 0.0, ucar = 0.0;
+    for (int ch = 1; ch >= 0; --ch) {
+        const int c0 = ch * CH + seg * SEG;
+        if (ch == 0) {
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) {
+                w[i] = pW[(seg * SEG + i) * TX + ixl]; Lv[i] = pL[(seg * SEG + i) * TX + ixl];
+                xv[i] = (need_dot && valid && c0 + i < n) ? ldg<NT>(x + base + (long)(c0 + i) * sl) : 0.0;
+            }
+            Lv[SEG] = seg < NS - 1 ? pL[(seg + 1) * SEG * TX + ixl] : sL1[ixl];   // written before the barriers in between
+            zin = pZ[si];
+            dinv_s = 0.0;
+            if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
+        }
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (valid && c < n) ? ldg<NT>(y + base + (long)c * sl) : 0.0; }
+        __syncthreads();                                         // the summaries of the previous sweep have been consumed
+        double Q = 1.0, lu = 0.0;
+#pragma unroll
+        for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
+        if (act) { sA[si] = Q; sB[si] = lu; }
+        if (act && ch == 0 && seg == 0) sC[ixl] = ucar;          // u entering chunk 0 from above: first face value of chunk 1
+        __syncthreads();
+        double u = ch == 1 ? 0.0 : sC[ixl];
+        for (int s = NS - 1; s > seg; --s) u = sA[s * TX + ixl] * u + sB[s * TX + ixl];
+#pragma unroll
+        for (int i = SEG - 1; i >= 0; --i) { u = w[i] - Lv[i + 1] * u; w[i] = u; }
+        ucar = w[0];
+        const double ulo = zin * dinv_s - Lv[0] * w[0];         // u at the lower face of this segment
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {                          // values first, branch-free, then the stores (see schur_s_tile)
+            const double lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
+            const bool in = valid && c0 + i < n;
+            yo[i] = yo[i] + Ta * (w[i] - lo); dot += in ? xv[i] * yo[i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) { const int c = c0 + i; if (valid && c < n) y[base + (long)c * sl] = yo[i]; }
+    }
+    if (need_dot) {
+        const double s = block_sum(dot, sred);
+        if (threadIdx.x == 0) partials[(long)by * gridDim.x + bx] = s;
     }
 }
 

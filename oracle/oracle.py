@@ -23,8 +23,10 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libnf_oracle.so")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "nf_oracle.c")):
+        # NF_ORACLE_LIB: another build of the same nf_oracle.c (tests/test_rounding_sensitivity.py compiles it with and without FMA
+        # contraction to measure how far two correct builds of the reference's algorithm end up apart)
+        path = os.environ.get("NF_ORACLE_LIB") or os.path.join(_HERE, "libnf_oracle.so")
+        if "NF_ORACLE_LIB" not in os.environ and (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "nf_oracle.c"))):
             build()
         L = C.CDLL(path)
         dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p

@@ -1,0 +1,76 @@
+"""Long y / z lines: the kernel branches BASELINE config 4 (synthetic 512^3) runs and every other length class of the
+segmented line kernels (neutfem_amd/csrc: launch_s / k_schur_s / the chunked long-line pass), against the oracle's
+SchurProduct (src/solvers.cpp:535-547) at 1e-12, plus a full SolveKeff on the C5 generator with 512-cell z lines."""
+import numpy as np
+import pytest
+
+from helpers import make_hip, make_oracle, rel_l2, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+# (nx, ny, nz): y or z lines of 505 ... 2100 cells on thin meshes -- 512 / 600 / 1023 / 1024 (one segment class), 576 and 1024
+# (the lengths the round-2 wavefront scan hung on: 72 ... 128 segments), 1100 / 2047 (16-cell segments), 2100 (32-cell segments)
+LONG = [(16, 16, 512), (24, 600, 3), (8, 8, 1024), (8, 576, 2), (40, 1023, 2), (3, 5, 1023), (8, 4, 1100), (6, 3, 2047), (4, 2100, 2),
+        (70, 512, 3), (33, 3, 640), (64, 2, 515)]
+
+
+def _apply(inp, rt=0, p=0, tol=1e-12, opts=None, groups=None):
+    o, s = make_oracle(inp, rt, p), make_hip(inp, rt, p)
+    for k, v in (opts or {}).items():
+        s.set_option(k, v)
+    rng = np.random.default_rng(3)
+    out = []
+    for g in (groups if groups is not None else range(int(inp["ng"]))):
+        x = rng.standard_normal(o.n_phi)
+        x[rng.random(o.n_phi) < 0.1] *= 1e-12
+        ya, yb = s.schur_apply(g, x), o.schur_apply(g, x)
+        assert np.isfinite(ya).all()
+        assert np.abs(ya - yb).max() <= tol * np.abs(yb).max(), (g, np.abs(ya - yb).max() / np.abs(yb).max())
+        out.append(ya)
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("shape", LONG)
+def test_schur_apply_long_lines(shape):
+    nx, ny, nz = shape
+    _apply(synthetic_inputs(nx, ny, nz, 2, seed=nx + 7 * ny + 13 * nz))
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 512), (12, 600, 2), (8, 8, 1024)])
+@pytest.mark.parametrize("opts", [dict(s_long=0), dict(s_long=0, s_wsmin=8), dict(s_long=0, s_wsmin=100000), dict(s_long=1), dict(s_long=1, s_tx=64), dict(s_long=1, s_tx=16)])
+def test_long_line_variants_agree(shape, opts):
+    """every variant a long line can take (classic one-chunk kernel with serial / wavefront-scanned segment summaries, chunked
+    long-line kernel at several tile widths) against the oracle, and bitwise-comparable among themselves to 1e-13"""
+    nx, ny, nz = shape
+    inp = synthetic_inputs(nx, ny, nz, 1, seed=11)
+    ya = _apply(inp, opts=opts)[0]
+    yb = _apply(inp, opts=dict(s_long=0, s_wsmin=100000))[0]
+    assert rel_l2(ya, yb) < 1e-13
+
+
+@pytest.mark.parametrize("rt,p", [(1, 1), (2, 2), (1, 0)])
+@pytest.mark.parametrize("shape", [(6, 300, 2), (5, 3, 600), (8, 512, 1), (4, 2, 1000)])
+def test_schur_apply_long_lines_higher_order(rt, p, shape):
+    nx, ny, nz = shape
+    _apply(synthetic_inputs(nx, ny, nz, 1, seed=nx + ny + nz + rt), rt, p)
+
+
+def test_solve_keff_c5_generator_512_cell_lines():
+    """the C5 generator (neutfem_amd.cases.synthetic_checkerboard: 16-cell checkerboard, one up-scatter block) cut to a 16 x 16 x 512
+    column -- 512-cell z lines as in the 512^3 benchmark -- full SolveKeff against the oracle:
+      (a) 8 groups, the bench's fixed work (exactly 50 CG iterations per group solve, 3 outers): same arithmetic path on both sides;
+      (b) 2 groups, 3 outers with the inner CG converged to 1e-10 (the iteration path does not depend on CG counts)."""
+    from neutfem_amd import cases
+    for ng, tol in [(8, (0.0, 0.0, 1e-4, 3, 50)), (2, (0.0, 1e-10, 1e-10, 3, 4000))]:
+        c = cases.synthetic_checkerboard(512, ng, nxy=16)
+        inp = dict(c, bc_attr=np.array([1, 2, 3, 4, 5, 6]), bc_type=np.zeros(6, int))
+        o, s = make_oracle(inp), make_hip(inp)
+        o.set_tol(*tol); s.set_tol(*tol)
+        ko = o.SolveKeff(); ks, n = s.solve_keff()
+        assert n == 3 and abs(ks - ko) / ko < 1e-9, (ng, ks, ko)
+        np.testing.assert_allclose(s.history()["k"], o.history()["k"], rtol=2e-9)
+        assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8, ng
+        if ng == 8:
+            assert np.array_equal(s.history()["cg"], o.history()["cg"])
+        s.close()
