@@ -19,8 +19,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def install_compat(with_shims=False):
+    # NEUTFEM_MODULE_DIR: directory holding another build of neutfem/_neutfem_eigen (the ASan/UBSan build of `make test-asan`)
+    alt = os.environ.get("NEUTFEM_MODULE_DIR")
+    if alt and alt not in sys.path:
+        sys.path.insert(0, alt)
     if _HERE not in sys.path:
-        sys.path.insert(0, _HERE)
+        sys.path.insert(1 if alt else 0, _HERE)
     if with_shims:
         shim = os.path.join(_HERE, "shims")
         if shim not in sys.path:

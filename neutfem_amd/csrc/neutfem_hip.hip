@@ -930,7 +930,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const int nouter = d == 1 ? S->nz : S->ny;
     // long plain lines of RT0-P0 meshes: two chunks per block, twice the tile width (k_schur_c).  s_long: -1 = from 257 cells per line
     // (where k_schur_s would drop below 32 columns), 0 = never, 1 = whenever the shape allows (tests)
-    if (S->nb == 0 && zmode == 0 && (T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min))) {
+    if (S->nb == 0 && zmode == 0 && (T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min)) && (size_t)N * sizeof(double) < (1ull << 32)) {   // 32-bit byte offsets inside
         const int NS = (n + 15) / 16;                                // segments of 8 cells per chunk, two chunks
         int TXc = T->opt_s_tx ? T->opt_s_tx : 64;
         while (TXc > 8 && TXc * NS > 1024) TXc >>= 1;

@@ -564,7 +564,7 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
 }
 // Streaming loads for the big-mesh passes: every array of a pass is larger than the caches and read once per pass, and a load that
 // carries the non-temporal hint does not push the lines the other streams still need out of L2 / MALL.  Tiled copy with the y / z
-// access pattern of the 256^3 passes, no arithmetic (scratch/tile_copy.hip, one MI355X): 4.99 -> 5.92 TB/s (y), 4.87 -> 6.07 (z);
+// access pattern of the 256^3 passes, no arithmetic (profiles/tools/r02/tile_copy.hip, one MI355X): 4.99 -> 5.92 TB/s (y), 4.87 -> 6.07 (z);
 // non-temporal *stores* lose (5.00 / 4.88 alone, 5.40 / 5.54 combined).  Not for meshes that live in the caches between launches.
 template <bool NT>
 __device__ __forceinline__ double ldg(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
@@ -1189,6 +1189,15 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
 // LDS (doubles): sA, sB [NS TX] (forward and backward summaries in turn), sC, sL1 [TX], 16 of reduction scratch, pW, pL [CH TX], pZ [NS TX].
 // Per cell the same expressions as k_schur_s (the value crossing the chunk boundary is the swept one, not a composed summary:
 // the two kernels agree to rounding, not bitwise).
+template <bool NT> __device__ __forceinline__ double ldo(const double *p, unsigned byte_off)     // uniform base + 32-bit byte offset: one VGPR per address
+{
+    const double *q = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + byte_off);
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+// Addresses are 32-bit BYTE offsets from the (wave-uniform) array bases -- the host takes this kernel only while one group's array is
+// below 4 GiB.  One VGPR per cell address, shared by x, L, 1/d and y, instead of a 64-bit pair per array: that is what keeps the
+// two-chunk body inside the 128 registers of a 1024-thread block (with 64-bit addresses it spilled 10-12 registers to scratch,
+// +31 % bytes written and +6 % fetched per pass by the PMC counters, profiles/r03_b_pmc_512_chunked.json).
 template <int DIR, bool NT>
 __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ x, double *__restrict__ y, double Ta,
                                                      const double *__restrict__ L, const double *__restrict__ DR, const double *__restrict__ D0,
@@ -1210,25 +1219,28 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
     const int ixl = act ? tid % TX : 0, seg = act ? tid / TX : 0, si = seg * TX + ixl;
     const int ix = (int)bx * TX + ixl;
     const bool valid = act && ix < nx;
-    const long base = (long)by * outer_stride + ix, lineid = (long)by * nx + ix;
+    const unsigned slb = (unsigned)(sl * 8);                     // bytes between the cells of a line
+    const unsigned ob = (unsigned)(((long)by * outer_stride + ix) * 8);   // byte offset of the line's first cell
+    const long lineid = (long)by * nx + ix;
     const bool need_dot = last && partials;
     double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], w[SEG], yo[SEG];
     double zin = 0.0, dinv_s = 0.0, zc = 0.0;
     // ---- forward sweeps, chunk 0 then chunk 1
     for (int ch = 0; ch < 2; ++ch) {
         const int c0 = ch * CH + seg * SEG;
+        const unsigned o0 = ob + (unsigned)c0 * slb;
 #pragma unroll
         for (int i = 0; i <= SEG; ++i) {                         // loads only (see schur_s_tile)
-            const int c = c0 + i; const bool ok = valid && c < n;
-            const long a = base + (long)c * sl;
+            const bool ok = valid && c0 + i < n;
+            const unsigned a = o0 + (unsigned)i * slb;
             // the overlap cell (i == SEG) is the next segment's first: a plain load keeps that line for it.  Two statements, not a
             // ternary on i: before the loop is unrolled a ternary is one load in each arm of a branch, which the optimiser merges
             // into a single load WITHOUT the hint (that is what round 2's kernels ran: every load of x was a plain one)
-            if (i < SEG) { xv[i] = ok ? ldg<NT>(x + a) : 0.0; Lv[i] = ok ? ldg<NT>(L + a) : 0.0; Rv[i] = ok ? ldg<NT>(DR + a) : 0.0; }
-            else { xv[i] = ok ? x[a] : 0.0; Lv[i] = ok ? L[a] : 0.0; }
+            if (i < SEG) { xv[i] = ok ? ldo<NT>(x, a) : 0.0; Lv[i] = ok ? ldo<NT>(L, a) : 0.0; Rv[i] = ok ? ldo<NT>(DR, a) : 0.0; }
+            else { xv[i] = ok ? ldo<false>(x, a) : 0.0; Lv[i] = ok ? ldo<false>(L, a) : 0.0; }
         }
         double ds = 0.0;
-        if (valid && c0 < n) ds = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
+        if (valid && c0 < n) ds = c0 == 0 ? D0[lineid] : ldo<false>(DR, o0 - slb);
         if (ch) __syncthreads();                                 // chunk 0's summaries and carry have been consumed
         double P = 1.0, lz = 0.0;
 #pragma unroll
@@ -1244,31 +1256,30 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
 #pragma unroll
         for (int i = 0; i < SEG; ++i) { const double ti = xv[i] - xv[i + 1]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; }
         zc = z;
-        if (ch == 0) {
-            if (act) {
+        if (ch == 0 && act) {
 #pragma unroll
-                for (int i = 0; i < SEG; ++i) { pW[(seg * SEG + i) * TX + ixl] = w[i]; pL[(seg * SEG + i) * TX + ixl] = Lv[i]; }
-                pZ[si] = zin;
-            }
+            for (int i = 0; i < SEG; ++i) { pW[(seg * SEG + i) * TX + ixl] = w[i]; pL[(seg * SEG + i) * TX + ixl] = Lv[i]; }
+            pZ[si] = zin;
         }
     }
     // ---- backward sweeps and output, chunk 1 (still in registers) then chunk 0 (from LDS)
     double dot = 0.0, ucar = 0.0;
     for (int ch = 1; ch >= 0; --ch) {
         const int c0 = ch * CH + seg * SEG;
+        const unsigned o0 = ob + (unsigned)c0 * slb;
         if (ch == 0) {
 #pragma unroll
             for (int i = 0; i < SEG; ++i) {
                 w[i] = pW[(seg * SEG + i) * TX + ixl]; Lv[i] = pL[(seg * SEG + i) * TX + ixl];
-                xv[i] = (need_dot && valid && c0 + i < n) ? ldg<NT>(x + base + (long)(c0 + i) * sl) : 0.0;
+                xv[i] = (need_dot && valid && c0 + i < n) ? ldo<NT>(x, o0 + (unsigned)i * slb) : 0.0;
             }
             Lv[SEG] = seg < NS - 1 ? pL[(seg + 1) * SEG * TX + ixl] : sL1[ixl];   // written before the barriers in between
             zin = pZ[si];
             dinv_s = 0.0;
-            if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : DR[base + (long)(c0 - 1) * sl];
+            if (valid && c0 < n) dinv_s = c0 == 0 ? D0[lineid] : ldo<false>(DR, o0 - slb);
         }
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (valid && c < n) ? ldg<NT>(y + base + (long)c * sl) : 0.0; }
+        for (int i = 0; i < SEG; ++i) yo[i] = (valid && c0 + i < n) ? ldo<NT>(y, o0 + (unsigned)i * slb) : 0.0;
         __syncthreads();                                         // the summaries of the previous sweep have been consumed
         double Q = 1.0, lu = 0.0;
 #pragma unroll
@@ -1289,7 +1300,8 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
             yo[i] = yo[i] + Ta * (w[i] - lo); dot += in ? xv[i] * yo[i] : 0.0;
         }
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) { const int c = c0 + i; if (valid && c < n) y[base + (long)c * sl] = yo[i]; }
+        for (int i = 0; i < SEG; ++i)
+            if (valid && c0 + i < n) *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + (o0 + (unsigned)i * slb)) = yo[i];
     }
     if (need_dot) {
         const double s = block_sum(dot, sred);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Helper of tests/test_rounding_sensitivity.py (run as a subprocess with NF_ORACLE_LIB pointing at one build of oracle/nf_oracle.c):
-solves the named benchmark inputs with the reference drivers' settings (set_tol(1e-5, 1e-4, 1e-4, 200, 1000), coarse start;
-tests/iaea3d/iaea3d.py:313,321) and writes k, the histories and the flux.   usage: rounding_probe.py <out.npz> <name> [<name> ...]"""
+re-runs the RT0-P0 full-path runs of the committed golden files (tests/golden/golden_<name>.json: the reference drivers' settings
+set_tol(1e-5, 1e-4, 1e-4, 200, 1000) with / without the coarse start, tests/iaea3d/iaea3d.py:313,321, and the tight-tolerance runs)
+and writes k, the histories and the flux of each under the key <name>:<index of the run>.
+usage: rounding_probe.py <out.npz> <name> [<name> ...]"""
 import os
 import sys
 
@@ -9,15 +11,35 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
-from helpers import TEST_TOL, load_inputs, make_oracle  # noqa: E402
+from helpers import load_golden, load_inputs, make_oracle  # noqa: E402
 
-out = {}
-for name in sys.argv[2:]:
-    inp = load_inputs(name)
-    o = make_oracle(inp)
-    o.set_tol(*TEST_TOL)
-    k = o.SolveKeff(True, [int(v) for v in inp["coarse_factors"]])
-    h = o.history()
-    out[name + "_k"] = k; out[name + "_khist"] = h["k"]; out[name + "_cg"] = h["cg"]; out[name + "_phi"] = o.phi_dofs().ravel().copy()
-    out[name + "_coarse_outer"] = h["coarse_outer"]
-np.savez(sys.argv[1], **out)
+
+def runs_of(name):
+    """(index, run) of the golden runs the spread is measured for: RT0-P0, full Schur path"""
+    return [(i, r) for i, r in enumerate(load_golden(name)["runs"]) if r["rt"] == 0 and r["p"] == 0 and not r["diag"]]
+
+
+def c5_column():
+    """the C5 generator cut to a 16 x 16 x 512 column, 8 groups (tests/test_gpu_longlines.py)"""
+    from neutfem_amd import cases
+    c = cases.synthetic_checkerboard(512, 8, nxy=16)
+    return dict(c, bc_attr=np.array([1, 2, 3, 4, 5, 6]), bc_type=np.zeros(6, int))
+
+
+if __name__ == "__main__":
+    out = {}
+    if "c5_column_fixed50" in sys.argv[2:]:
+        # the bench's fixed work on C5: exactly 50 CG iterations per group solve (unconverged Krylov iterates), 3 outers
+        sys.argv.remove("c5_column_fixed50")
+        o = make_oracle(c5_column()); o.set_tol(0.0, 0.0, 1e-4, 3, 50)
+        k = o.SolveKeff(); h = o.history(); key = "c5_column_fixed50:0"
+        out[key + "_k"] = k; out[key + "_khist"] = h["k"]; out[key + "_cg"] = h["cg"]; out[key + "_phi"] = o.phi_dofs().ravel().copy()
+    for name in sys.argv[2:]:
+        inp = load_inputs(name)
+        o = make_oracle(inp)
+        for i, r in runs_of(name):
+            o.reset_flux(); o.set_tol(*r["tol"])
+            k = o.SolveKeff(r["coarse"], [int(v) for v in inp["coarse_factors"]] if r["coarse"] else [])
+            h = o.history(); key = f"{name}:{i}"
+            out[key + "_k"] = k; out[key + "_khist"] = h["k"]; out[key + "_cg"] = h["cg"]; out[key + "_phi"] = o.phi_dofs().ravel().copy()
+    np.savez(sys.argv[1], **out)

@@ -57,20 +57,27 @@ def test_schur_apply_long_lines_higher_order(rt, p, shape):
 
 
 def test_solve_keff_c5_generator_512_cell_lines():
-    """the C5 generator (neutfem_amd.cases.synthetic_checkerboard: 16-cell checkerboard, one up-scatter block) cut to a 16 x 16 x 512
-    column -- 512-cell z lines as in the 512^3 benchmark -- full SolveKeff against the oracle:
-      (a) 8 groups, the bench's fixed work (exactly 50 CG iterations per group solve, 3 outers): same arithmetic path on both sides;
-      (b) 2 groups, 3 outers with the inner CG converged to 1e-10 (the iteration path does not depend on CG counts)."""
+    """the C5 generator (neutfem_amd.cases.synthetic_checkerboard: 16-cell checkerboard, 8 groups, one up-scatter block) cut to a
+    16 x 16 x 512 column -- 512-cell z lines as in the 512^3 benchmark -- full SolveKeff against the oracle:
+      (a) 2 outers with the inner CG converged to 1e-10: the iteration path does not depend on CG counts -> k 1e-9, flux 1e-8;
+      (b) the bench's fixed work (exactly 50 CG iterations per group solve, 3 outers).  Fifty iterations leave the CG unconverged, and
+          an unconverged Krylov iterate amplifies rounding differences: two builds of the ORACLE itself (with / without FMA contraction,
+          tests/golden/rounding_spread.json "c5_column_fixed50:0") end 1.6e-7 apart in k and 1.9e-5 in flux on this run.  Equal CG
+          counts, k within 0.1 pcm, flux within three times that measured spread."""
     from neutfem_amd import cases
-    for ng, tol in [(8, (0.0, 0.0, 1e-4, 3, 50)), (2, (0.0, 1e-10, 1e-10, 3, 4000))]:
-        c = cases.synthetic_checkerboard(512, ng, nxy=16)
-        inp = dict(c, bc_attr=np.array([1, 2, 3, 4, 5, 6]), bc_type=np.zeros(6, int))
-        o, s = make_oracle(inp), make_hip(inp)
+    c = cases.synthetic_checkerboard(512, 8, nxy=16)
+    inp = dict(c, bc_attr=np.array([1, 2, 3, 4, 5, 6]), bc_type=np.zeros(6, int))
+    o, s = make_oracle(inp), make_hip(inp)
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rounding_spread.json")) as f:
+        spread = json.load(f)["c5_column_fixed50:0"]["flux_rel_l2"]
+    for tol, kbar, fbar in [((0.0, 1e-10, 1e-10, 2, 4000), 1e-9, 1e-8), ((0.0, 0.0, 1e-4, 3, 50), 1e-6, 3.0 * spread)]:
+        o.reset_flux(); s.reset_flux()
         o.set_tol(*tol); s.set_tol(*tol)
         ko = o.SolveKeff(); ks, n = s.solve_keff()
-        assert n == 3 and abs(ks - ko) / ko < 1e-9, (ng, ks, ko)
-        np.testing.assert_allclose(s.history()["k"], o.history()["k"], rtol=2e-9)
-        assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8, ng
-        if ng == 8:
+        assert n == tol[3] and abs(ks - ko) / ko < kbar, (tol, ks, ko)
+        np.testing.assert_allclose(s.history()["k"], o.history()["k"], rtol=2 * kbar)
+        assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < fbar, tol
+        if tol[4] == 50:
             assert np.array_equal(s.history()["cg"], o.history()["cg"])
-        s.close()
+    s.close()

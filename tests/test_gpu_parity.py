@@ -124,7 +124,13 @@ def test_cg_solve_group(name):
     s.close()
 
 
-def _keff_case(name, run):
+def _spread(key):
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rounding_spread.json")) as f:
+        return json.load(f)[key]
+
+
+def _keff_case(name, run, idx):
     """HIP SolveKeff vs the committed golden vector AND vs the oracle run live on the same input.
 
     k-eff must agree within 1 pcm always.  The flux bar of 1e-8 applies when both sides followed the same
@@ -149,13 +155,15 @@ def _keff_case(name, run):
         assert abs(n - run["n_outer"]) <= max(1, 0.05 * run["n_outer"]), (n, run["n_outer"])
         m = min(n, run["n_outer"])
         assert abs(int(h["cg"][:m].sum()) - int(gold_cg[:m].sum())) <= 0.15 * gold_cg[:m].sum()
-    tol_flux = run["tol"][1]
-    # same path: 1e-8.  Different path (IAEA-3D only): each run is converged to about tol_flux / (1 - dominance ratio) -- 5e-8 at the 1e-9 of
-    # the tight golden run (measured 1.5e-8 with outer counts 120 / 124), 2 tol_flux at the drivers' 1e-4
-    bar = 1e-8 if same_path else (50.0 * tol_flux if tol_flux <= 1e-9 else 2.0 * tol_flux)
+    # same path: 1e-8.  Different path (IAEA-3D only): the bar is MEASURED, not guessed -- three times the distance at which two correct
+    # builds of the oracle itself (with / without FMA contraction, tests/test_rounding_sensitivity.py -> tests/golden/rounding_spread.json)
+    # end on this very run: 6.6e-5 / 6.5e-5 on IAEA-3D 38x38x19 with / without coarse start, 1.5e-7 on the 1x1 mesh, 1.5e-8 on its tight run
+    bar = 1e-8 if same_path else max(1e-8, 3.0 * _spread(f"{name}:{idx}")["flux_rel_l2"])
     m = min(n, run["n_outer"])
     np.testing.assert_allclose(h["k"][:m], run["k_hist"][:m], rtol=1e-9 if same_path else 5e-5)   # intermediate iterates: tolerance-limited
-    assert rel_l2(phi[::run["phi_stride"]], run["phi_samples"]) < bar
+    d_gold = rel_l2(phi[::run["phi_stride"]], run["phi_samples"])
+    print(f"{name}:{idx} same_path={same_path} flux rel-L2 vs golden {d_gold:.3e} (bar {bar:.1e}), k {k:.10f} vs {run['keff']:.10f}, outers {n} vs {run['n_outer']}")
+    assert d_gold < bar
     o = make_oracle(inp)
     o.set_tol(*run["tol"])
     ko = o.SolveKeff(run["coarse"], [int(v) for v in inp["coarse_factors"]] if run["coarse"] else [], run["diag"])
@@ -166,13 +174,15 @@ def _keff_case(name, run):
 
 
 def _rt0_runs(name):
-    return [r for r in load_golden(name)["runs"] if r["rt"] == 0 and r["p"] == 0]
+    """(index in the golden file, run): the index is the key of the run's measured rounding spread"""
+    return [(i, r) for i, r in enumerate(load_golden(name)["runs"]) if r["rt"] == 0 and r["p"] == 0]
 
 
 @pytest.mark.parametrize("name,idx", [(n, i) for n in ["iaea2d", "iaea3d", "iaea3d_1x1", "koeberg2d", "biblis2d", "zion2d"]
                                       for i in range(len(_rt0_runs(n)))])
 def test_solve_keff_golden(name, idx):
-    _keff_case(name, _rt0_runs(name)[idx])
+    i, run = _rt0_runs(name)[idx]
+    _keff_case(name, run, i)
 
 
 def test_iaea3d_tight_tolerance_flux_parity():
@@ -238,7 +248,7 @@ def test_pybind_module_end_to_end():
     m.BuildMatrices()
     m.set_tol(*TEST_TOL)
     k = m.SolveKeff(use_coarse_init=True, coarse_factors=[2, 2, 1])
-    run = _rt0_runs("iaea2d")[0]
+    run = _rt0_runs("iaea2d")[0][1]
     assert abs(k - run["keff"]) / run["keff"] < PCM
     phi = m.get_flux()
     assert phi.shape == (2, 38, 38)
@@ -352,11 +362,12 @@ def test_iaea3d_128cube_golden(fuse3):
     # one kernel, same operator to 1e-12 -- misses it with dphi = 1.2e-4 and runs to outer 34).  Both answers are converged to the
     # tolerance: k agrees to 1.2 pcm, and that is what is asserted; the tight comparison is the `fixed` run above.
     assert 0.6 * r["n_outer"] <= n <= 2.0 * r["n_outer"], (n, r["n_outer"])
-    assert abs(k - r["keff"]) / r["keff"] < PCM + 2.0 * r["tol"][0], (k, r["keff"], n, r["n_outer"])
+    sp = _spread("iaea3d_128cube_driver")                            # two builds of the ORACLE on this run: flux 4.3e-4 apart, k 0.72 pcm, outers 23 / 24
+    assert abs(k - r["keff"]) / r["keff"] < max(PCM, 2.0 * sp["k_pcm"] * 1e-5), (k, r["keff"], n, r["n_outer"])
     # a power iteration stopped at dphi < tol_flux is converged to about tol_flux / (1 - dominance ratio) only, and on this input the inner
     # CG counts are rounding-sensitive (void cells): two correct runs end 4e-4 apart at the drivers' 1e-4 (measured); the tight bar is the
     # `fixed` run above, where the iteration path is pinned
     d = rel_l2(s.get_phi().ravel()[::r["phi_stride"]], r["phi_samples"])
     print(f"128^3 driver settings: flux rel-L2 vs oracle {d:.2e} (tol_flux {r['tol'][1]:.0e}), k {k:.9f} vs {r['keff']:.9f}, outers {n} vs {r['n_outer']}")
-    assert d < 10.0 * r["tol"][1]
+    assert d < 3.0 * sp["flux_rel_l2"]                               # measured oracle-vs-oracle spread (tests/golden/make_rounding_spread_128cube.py), not a guess
     s.close()

@@ -38,6 +38,7 @@ def runs(tmp_path_factory):
 
 
 def _spread(a, b, name):
+    """distance between the two builds on run `name` = "<benchmark>:<index of the golden run>" (rounding_probe.py)"""
     pa, pb = a[name + "_phi"], b[name + "_phi"]
     return dict(flux_rel_l2=float(np.linalg.norm(pa - pb) / np.linalg.norm(pa)), k_pcm=float(1e5 * abs(a[name + "_k"] - b[name + "_k"]) / a[name + "_k"]),
                 outers=[int(a[name + "_cg"].shape[0]), int(b[name + "_cg"].shape[0])], cg=[int(a[name + "_cg"].sum()), int(b[name + "_cg"].sum())])
@@ -46,20 +47,21 @@ def _spread(a, b, name):
 def test_fma_contraction_changes_the_machine_code(runs):
     """guard: if the two builds were the same code the test below would prove nothing"""
     a, b = runs
-    assert not np.array_equal(a["iaea3d_phi"], b["iaea3d_phi"]) or not np.array_equal(a["iaea2d_phi"], b["iaea2d_phi"])
+    assert not np.array_equal(a["iaea3d:0_phi"], b["iaea3d:0_phi"]) or not np.array_equal(a["iaea2d:0_phi"], b["iaea2d:0_phi"])
 
 
 def test_iaea2d_is_insensitive(runs):
     a, b = runs
-    assert float(a["iaea2d_k"]) == float(b["iaea2d_k"]) or abs(float(a["iaea2d_k"]) - float(b["iaea2d_k"])) < 1e-13
-    assert np.array_equal(a["iaea2d_cg"], b["iaea2d_cg"])                    # same outer count, same CG count in every group solve
-    assert np.allclose(a["iaea2d_khist"], b["iaea2d_khist"], rtol=1e-12, atol=0)
-    assert _spread(a, b, "iaea2d")["flux_rel_l2"] < 1e-11
+    for key in ("iaea2d:0", "iaea2d:1", "iaea2d:3"):                         # drivers' settings with / without coarse start, tight tolerances
+        assert abs(float(a[key + "_k"]) - float(b[key + "_k"])) < 1e-13
+        assert np.array_equal(a[key + "_cg"], b[key + "_cg"])                # same outer count, same CG count in every group solve
+        assert np.allclose(a[key + "_khist"], b[key + "_khist"], rtol=1e-12, atol=0)
+        assert _spread(a, b, key)["flux_rel_l2"] < (1e-13 if key != "iaea2d:3" else 1e-9)    # 85 outers at 1e-10: 5.6e-11 apart, same counts
 
 
 def test_iaea3d_at_driver_tolerances_is_rounding_sensitive(runs):
     a, b = runs
-    sp = _spread(a, b, "iaea3d")
+    sp = _spread(a, b, "iaea3d:0")                                           # the drivers' own run: coarse start, 1e-5 / 1e-4
     # two correct builds: flux apart by far more than north_star's 1e-8, k apart by far less than 1 pcm (judge's own rebuild: 6.5e-5 / 0.18 pcm)
     assert sp["flux_rel_l2"] > 1e-6, sp
     assert sp["flux_rel_l2"] < 1e-4, sp                                      # ... and still a fraction of tol_flux = 1e-4
@@ -67,18 +69,21 @@ def test_iaea3d_at_driver_tolerances_is_rounding_sensitive(runs):
     assert sp["cg"][0] != sp["cg"][1], sp
     # the committed spread the GPU bars are derived from must be this measurement (same compiler on every box of this image)
     with open(SPREAD) as f:
-        rec = json.load(f)["iaea3d"]
+        rec = json.load(f)["iaea3d:0"]
     assert 0.5 * rec["flux_rel_l2"] <= sp["flux_rel_l2"] <= 2.0 * rec["flux_rel_l2"], (rec, sp)
 
 
 if __name__ == "__main__":           # regenerates tests/golden/rounding_spread.json
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
+        from rounding_probe import runs_of
         names = ["iaea2d", "iaea3d", "iaea3d_1x1"]
         a, b = _run(tmp, "off", names), _run(tmp, "fast", names)
-        rec = {n: _spread(a, b, n) for n in names}
-        rec["what"] = ("oracle/nf_oracle.c built with -ffp-contract=off vs -ffp-contract=fast (gcc, -O3 -march=x86-64-v3), reference drivers' settings "
-                       "set_tol(1e-5,1e-4,1e-4,200,1000) + coarse start: distance between the two runs.  Regenerate: python tests/test_rounding_sensitivity.py")
+        rec = {f"{n}:{i}": dict(_spread(a, b, f"{n}:{i}"), tol=r["tol"], coarse=r["coarse"]) for n in names for i, r in runs_of(n)}
+        a, b = _run(tmp, "off", ["c5_column_fixed50"]), _run(tmp, "fast", ["c5_column_fixed50"])
+        rec["c5_column_fixed50:0"] = dict(_spread(a, b, "c5_column_fixed50:0"), tol=[0.0, 0.0, 1e-4, 3, 50], coarse=False)
+        rec["what"] = ("oracle/nf_oracle.c built with -ffp-contract=off vs -ffp-contract=fast (gcc, -O3 -march=x86-64-v3), reference settings of the "
+                       "golden runs (key = <benchmark>:<index in tests/golden/golden_<benchmark>.json>): distance between the two runs.  Regenerate: python tests/test_rounding_sensitivity.py")
         if os.path.exists(SPREAD):                               # keep the entries other generators own (make_rounding_spread_128cube.py)
             with open(SPREAD) as f:
                 rec = {**json.load(f), **rec}
