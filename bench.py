@@ -45,7 +45,39 @@ def parse():
     ap.add_argument("--no-small", action="store_true", help="skip the small BASELINE configs (0-2)")
     ap.add_argument("--no-c5", action="store_true", help="skip the extra line for BASELINE config 4 (synthetic 512^3 x 8 groups on this one GPU)")
     ap.add_argument("--loopback-slabs", type=int, default=1, help="z-slabs per process (>1: exercise the slab path on one GPU)")
+    ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("NEUTFEM_WATCHDOG_S", "300")),
+                    help="multi-rank runs: exit non-zero when no outer iteration completes within this many seconds (a peer is gone or stuck)")
     return ap.parse_args()
+
+
+class Watchdog:
+    """Per-rank guard of a multi-rank run: a daemon thread polls nf_progress (outer iterations completed by the running solve) and ends
+    THIS process with exit code 3 -- a fresh exit, never a re-exec of a process that has touched the GPU -- when the count has not
+    moved for `limit` seconds while a solve is armed.  torchrun then tears the other ranks down; with the library's own collective
+    timeout (NEUTFEM_COMM_TIMEOUT_S) no rank can sit in a collective for ever because one peer died."""
+
+    def __init__(self, solver, limit, rank):
+        import threading
+        self.s, self.limit, self.rank, self.armed, self.stop = solver, limit, rank, False, False
+        self.t = threading.Thread(target=self.run, daemon=True); self.t.start()
+
+    def arm(self, on):
+        self.last, self.t0, self.armed = -1, time.monotonic(), on
+
+    def run(self):
+        while not self.stop:
+            time.sleep(min(2.0, max(0.05, self.limit / 10.0)))
+            if not self.armed:
+                continue
+            try:
+                n = self.s.progress()
+            except Exception:
+                continue
+            if n != self.last:
+                self.last, self.t0 = n, time.monotonic()
+            elif time.monotonic() - self.t0 > self.limit:
+                print(f"[bench watchdog] rank {self.rank}: no outer iteration completed for {self.limit:.0f} s (stuck at {n}): exiting", file=sys.stderr, flush=True)
+                os._exit(3)
 
 
 def make_solver(case, device):
@@ -195,6 +227,10 @@ def main():
             dist.barrier()
         head._chk(head.L.nf_synchronize(head.h))               # stream + device synchronize
 
+    dog = Watchdog(head, a.watchdog_s, rank) if world > 1 else None
+    if dog:
+        dog.arm(True)
+
     # warm-up: W untimed outer iterations (also warms caches / clocks); state carries over like the reference
     if a.warmup > 0:
         s.set_tol(0.0, TOL_FLUX, 1e-4, a.warmup, MAX_INNER)
@@ -220,7 +256,7 @@ def main():
     else:
         nzl, nxl, nyl, Nl = s.nz, s.nx, s.ny, N
     nJd = {0: (nxl + 1) * nyl * nzl, 1: nxl * (nyl + 1) * nzl, 2: nxl * nyl * (nzl + 1)}
-    kern = {0: "k_schur_x<2,NCH,VEC>", 1: "k_schur_s<SEG,1> (y lines)", 2: "k_schur_s<SEG,2> (z lines)"}
+    kern = {0: "k_schur_x<2,NCH,VEC>", 1: "k_schur_s<SEG,1> / k_schur_c<1> (y lines)", 2: "k_schur_s<SEG,2> / k_schur_c<2> (z lines)"}
     passes = []
     # fused CG (undivided RT0-P0 mesh): the x pass also carries x_sol += alpha p and p = r + beta p of the previous
     # iteration (read r, x_sol; write p, x_sol = 32 B/cell on top of the apply; p itself is read once for both jobs) on every
@@ -253,7 +289,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", prof)) as f:
             pj = json.load(f)
         pmc = pj["kernels"]
-        pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_s<\d+, 1,", "schur_z": r"k_schur_s<\d+, 2,", "schur_apply": r"k_apply3<"}[dom["name"]]
+        pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_[sc]<(\d+, )?1,", "schur_z": r"k_schur_[sc]<(\d+, )?2,", "schur_apply": r"k_apply3<"}[dom["name"]]
         hits = [k for k in pmc if re.match(pat, k)]
         key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None
         if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:
@@ -393,6 +429,8 @@ def main():
             out["parity"] = dict(mesh="38x38x19", keff_gpu=kg, keff_oracle=ko, pcm=round(1e5 * abs(kg - ko) / ko, 6),
                                  flux_rel_l2=float(np.linalg.norm(pg - po) / np.linalg.norm(po)))
             sp.close()
+    if dog:
+        dog.arm(False); dog.stop = True
     s.close()
     # ---- BASELINE configs[4] (synthetic 512^3, 8 groups, fixed work of 50 CG iterations per group solve) on this ONE GPU,
     # so that the driver's run times it too.  Needs ~165 GB of HBM and ~75 GB of host memory for the case arrays: skipped when the
@@ -422,7 +460,32 @@ def main():
                 out["c5_single_gpu"] = dict(workload=c5["name"] + ", full Schur path, exactly 50 CG iterations per group solve", cells=int(N5), groups=8,
                                             steps=int(n5), value=round(n5 / t5, 4), unit="outer-iters/s", ms_per_step=round(t5 / n5 * 1e3, 1),
                                             keff_after_steps=k5, passes=ps, peak_GBps=HBM_PEAK_GBS)
+                # no number without a check: (i) size-independent properties of S_g at the full 512^3 (linear, symmetric, positive) on the very
+                # kernels that were timed; (ii) S_g x against the CPU oracle for all 8 groups on a 32 x 32 x 512 column of the same generator
+                # (512-cell z lines: the same long-line kernel, the same segment / chunk structure along z)
+                note("C5 self-check")
+                rng5 = np.random.default_rng(5)
+                xa, xb = rng5.standard_normal(N5), rng5.standard_normal(N5)
+                par = dict(groups_checked=[0, 7])
+                lin, sym, pos = 0.0, 0.0, True
+                for g5 in (0, 7):
+                    Sa, Sb = s5.schur_apply(g5, xa), s5.schur_apply(g5, xb)
+                    Sab = s5.schur_apply(g5, 2.0 * xa - 3.0 * xb)
+                    lin = max(lin, float(np.linalg.norm(Sab - (2.0 * Sa - 3.0 * Sb)) / np.linalg.norm(Sab)))
+                    sym = max(sym, float(abs(xb @ Sa - xa @ Sb) / abs(xb @ Sa)))
+                    pos = pos and bool(xa @ Sa > 0 and xb @ Sb > 0)
+                    del Sa, Sb, Sab
+                par.update(linearity_rel_l2=lin, symmetry_rel=sym, positive=pos)
+                del xa, xb
                 s5.close()
+                col = cases.synthetic_checkerboard(512, 8, nxy=32)
+                sc_, oc_ = make_solver(col, local), make_oracle(col)
+                xr = np.random.default_rng(6).standard_normal(oc_.n_phi)
+                par["column_32x32x512_vs_oracle_max_rel_err"] = max(float(np.abs(sc_.schur_apply(g5, xr) - oc_.schur_apply(g5, xr)).max() / np.abs(oc_.schur_apply(g5, xr)).max())
+                                                                 for g5 in range(8))
+                sc_.close(); del oc_
+                par["ok"] = bool(lin < 1e-12 and sym < 1e-10 and pos and par["column_32x32x512_vs_oracle_max_rel_err"] < 1e-12)
+                out["c5_single_gpu"]["parity"] = par
             else:
                 out["c5_single_gpu"] = dict(skipped=f"needs >= 180 GB free HBM and >= 110 GB free host memory (have {free_b / 1e9:.0f} / {avail_kb * 1024 / 1e9:.0f})")
         except Exception as e:                                                          # never lose the headline line to the extra one

@@ -24,7 +24,9 @@ extern "C" {
 typedef struct nf_solver *nf_handle;
 
 enum { NF_OK = 0, NF_ERR_ARG = -1, NF_ERR_NO_DEVICE = -2, NF_ERR_HIP = -3, NF_ERR_UNSUPPORTED = -4,
-       NF_ERR_STATE = -5, NF_ERR_NUMERIC = -6 };
+       NF_ERR_STATE = -5, NF_ERR_NUMERIC = -6,
+       NF_ERR_REMOTE = -7,   /* multi-rank team: another rank hit an error inside a solve; every rank returns at the same iteration */
+       NF_ERR_COMM = -8 };   /* multi-rank team: a collective did not complete within NEUTFEM_COMM_TIMEOUT_S (a peer is gone or stuck) */
 /* BCType, include/NeutFEM.hpp:51-57 */
 enum { NF_BC_DIRICHLET = 0, NF_BC_NEUMANN = 1, NF_BC_MIRROR = 2, NF_BC_ROBIN = 3, NF_BC_PERIODIC = 4 };
 
@@ -114,6 +116,13 @@ typedef struct nf_keff_opts {
  * (src/NeutFEM.cpp:2084-2105).  State kept between calls exactly like the reference:
  * current flux (nf_set_phi/nf_get_phi) and has_valid_keff_/last_keff_direct_. */
 int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_outer);
+
+/* No reference counterpart (the reference is one process): outer iterations the running or last nf_solve_keff has completed
+ * (the `it` of the loop at src/NeutFEM.cpp:1694).  May be called from another thread while nf_solve_keff runs -- the watchdog
+ * of a multi-rank job tells a slow solve from one whose peers are gone.  On a multi-rank team a rank that fails inside a solve
+ * makes every rank return (the failing one with its own code, the others with NF_ERR_REMOTE); a collective that does not complete
+ * within NEUTFEM_COMM_TIMEOUT_S seconds (default 600) returns NF_ERR_COMM. */
+int nf_progress(nf_handle h, long *outers_done);
 
 /* CMFD acceleration (src/NeutFEM.cpp:662-1017, include/NeutFEM.hpp:119-143,232-235): NeutFEM::InitializeCMFD
  * (D-tilde for every direction, D-hat = 0; idempotent until the next nf_build), SetCMFDRelaxation, and a probe that

@@ -15,7 +15,7 @@ SYMBOLS = [
     "nf_comm_init", "nf_comm_selftest", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_coarsen", "nf_prolong", "nf_timers", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
-    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy",
+    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy", "nf_progress",
     "nf_set_option", "nf_mem_info", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
 
@@ -79,6 +79,7 @@ def load():
     L.nf_profile_reset.argtypes = [vp]
     L.nf_time_schur_apply.argtypes = [vp, C.c_int, C.c_int, dp]
     L.nf_time_device_copy.argtypes = [vp, C.c_size_t, C.c_int, dp]
+    L.nf_progress.argtypes = [vp, C.POINTER(C.c_long)]
     L.nf_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.nf_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.nf_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -286,6 +287,10 @@ class HipSolver:
 
     def time_schur_apply(self, g, reps):
         ms = C.c_double(); self._chk(self.L.nf_time_schur_apply(self.h, g, reps, C.byref(ms))); return ms.value
+
+    def progress(self):
+        """completed outer iterations of the running / last solve_keff (callable from another thread)"""
+        v = C.c_long(); self._chk(self.L.nf_progress(self.h, C.byref(v))); return v.value
 
     def time_device_copy(self, nbytes, reps=20):
         v = C.c_double(); self._chk(self.L.nf_time_device_copy(self.h, int(nbytes), reps, C.byref(v))); return v.value

@@ -14,6 +14,7 @@
 #include "nf_kernels.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -69,6 +70,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;          // optional: used when a peer stops answering (comm_timeout_s)
 };
 static Rccl g_rccl;
 static const int NCCL_DOUBLE = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclFloat64 / ncclSum / ncclMax in rccl.h
@@ -88,6 +90,7 @@ static int rccl_load()
     SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart");
     SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void **)(&g_rccl.CommAbort) = dlsym(g_rccl.lib, "ncclCommAbort");
     return NF_OK;
 }
 
@@ -104,7 +107,18 @@ struct nf_team {
     double *d_partials = nullptr; long partial_stride = 0, slab_cap = 0;
     CgScalars *d_cg = nullptr;
     double *d_out = nullptr;        // 4 doubles read by the host each outer
-    double *d_red = nullptr;        // 4 doubles: process-local sums awaiting the all-reduce
+    double *d_red = nullptr;        // 8 doubles: process-local sums awaiting the all-reduce, each followed by this rank's error flag
+    // A rank that fails locally inside a solve must not leave the others waiting in the next collective:
+    // it raises d_errsrc (k_finalize appends it to every reduction that crosses ranks; the consumers stop every rank with
+    // CgScalars::err), keeps issuing the collectives of the schedule without the compute ("poisoned"), and returns its own error
+    // once the flag has come back; the other ranks return NF_ERR_REMOTE at the same iteration.
+    double *d_errsrc = nullptr;     // 1 double, 0 = fine
+    bool poisoned = false; int poison_rc = 0; char poison_msg[256] = { 0 };
+    int xchg_in_apply = 0;          // interface exchanges issued since the current Schur apply began
+    long cg_iter_total = 0;         // CG iterations launched since the team was created (NEUTFEM_INJECT_FAIL=<rank>:<iteration>)
+    int inject_rank = -1; long inject_iter = -1;
+    double comm_timeout_s = 600.0;  // multi-rank teams: a stream that does not drain for this long means a peer is gone (NEUTFEM_COMM_TIMEOUT_S)
+    volatile long outers_done = 0;  // completed outer iterations of the running / last SolveKeff (bench.py's watchdog polls it from another thread)
     bool linked_ready = false;      // separator diagonals exchanged
     int sep_sweeps = 0;             // Jacobi sweeps on the separator system (0: slabs thick enough for it to be diagonal to rounding)
     std::vector<int> last_its;
@@ -125,6 +139,7 @@ struct nf_team {
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
+    int opt_split_dot = 1;                                // big undivided RT0-P0 meshes: per-pass shares of p.q (team_schur_apply)
     int opt_s_long = -1, s_long_min = 256;                // chunked long-line pass (k_schur_c): -1 auto (lines longer than s_long_min), 0 off, 1 always
     size_t lds_limit = 160 * 1024;                        // dynamic LDS a block may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock at team creation)
     // fused-direction CG (two launches per iteration) up to this many cells.  Measured crossover against the four-launch lean path after
@@ -181,6 +196,7 @@ struct nf_solver {
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
     CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
     CgLean lean_z1 = { nullptr, nullptr, 0, 0, 0 };     // slab teams: the endpoint pass of the z lines consumes the all-reduced |r|^2
+    bool zw_dot = false;                                // this apply: the y / z passes emit T_a sum z_f w_f as their share of x.y (team_schur_apply, split)
     double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nJz face DOFs (nf_get_J)
     double *d_Jzb = nullptr;                            // slabs, RT1+: z bubbles of the local cells, ng * N * ni
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
@@ -306,7 +322,10 @@ static int team_alloc(nf_team *T)
     NFCHK(dalloc(&T->d_partials, (size_t)T->partial_stride * 4));
     if (!T->d_cg) NFCHK(dalloc(&T->d_cg, 1));
     if (!T->d_out) NFCHK(dalloc(&T->d_out, 8));
-    if (!T->d_red) NFCHK(dalloc(&T->d_red, 4));
+    if (!T->d_red) NFCHK(dalloc(&T->d_red, 8));
+    if (!T->d_errsrc) { NFCHK(dalloc(&T->d_errsrc, 1)); HIPCHK(hipMemset(T->d_errsrc, 0, sizeof(double))); }
+    if (const char *e = getenv("NEUTFEM_INJECT_FAIL")) { int r = -1; long it = -1; if (sscanf(e, "%d:%ld", &r, &it) == 2) { T->inject_rank = r; T->inject_iter = it; } }
+    if (const char *e = getenv("NEUTFEM_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0) T->comm_timeout_s = v; }
     T->last_its.assign(64, 0);
     return NF_OK;
 }
@@ -318,7 +337,7 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
-    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
+    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_errsrc); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
     if (T->h_pub) (void)hipHostFree(T->h_pub);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
     if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
@@ -690,6 +709,25 @@ static hipError_t stream_wait(hipStream_t st)
     return hipStreamSynchronize(st);
 }
 
+// Wait for the solver's stream.  On a multi-rank team the stream holds collectives: if it does not drain within comm_timeout_s a peer
+// is gone or stuck, and blocking for ever would pin this rank (and, under torchrun, the whole node) -- abort the communicator and
+// return NF_ERR_COMM instead.
+static int team_stream_wait(nf_team *T, hipStream_t st)
+{
+    if (T->nproc <= 1) { HIPCHK(stream_wait(st)); return NF_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long i = 0;; ++i) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return NF_OK;
+        if (q != hipErrorNotReady) { HIPCHK(q); }
+        if (i > 2000) usleep(i > 20000 ? 200 : 20);
+        if ((i & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > T->comm_timeout_s) {
+            if (g_rccl.CommAbort && T->comm) { (void)g_rccl.CommAbort(T->comm); T->comm = nullptr; }
+            return fail(NF_ERR_COMM, "rank %d: a collective did not complete within %.0f s (NEUTFEM_COMM_TIMEOUT_S): a peer rank is gone or stuck", T->rank, T->comm_timeout_s);
+        }
+    }
+}
+
 // Read the CG scalars and / or nout doubles of `out` back to the host: through the mapped page when available, else D2H copy + wait.
 static bool pub_ready(nf_team *T)                                 // the mapped page exists (created on first use)
 {
@@ -713,7 +751,7 @@ static int pub_wait(nf_team *T, unsigned long long seq, CgScalars *h_cg, double 
         if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
     }
     if (!seen) {                                                  // long wait (big mesh) or an error: block, then look again
-        HIPCHK(hipStreamSynchronize(T->stream));
+        NFCHK(team_stream_wait(T, T->stream));
         if (__atomic_load_n(&T->h_pub->seq, __ATOMIC_ACQUIRE) != seq) return fail(NF_ERR_HIP, "scalar readback: the device never published sequence %llu", seq);
     }
     if (h_cg) *h_cg = T->h_pub->cg;
@@ -730,7 +768,7 @@ static int readback(nf_team *T, const CgScalars *d_cg, CgScalars *h_cg, const do
     }
     if (h_cg) HIPCHK(hipMemcpyAsync(h_cg, d_cg, sizeof *h_cg, hipMemcpyDeviceToHost, st));
     if (nout > 0) HIPCHK(hipMemcpyAsync(h_out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(stream_wait(st));
+    NFCHK(team_stream_wait(T, st));
     return NF_OK;
 }
 
@@ -763,6 +801,7 @@ static void prof_collect(nf_team *T)
 static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
 {
     const int ns = (int)T->slabs.size();
+    ++T->xchg_in_apply;
     auto send_lo = [&](nf_solver *S) { return which == 0 ? S->d_clo : which == 2 ? S->d_elo : S->d_hlo + (size_t)g * S->nlines[2]; };
     auto send_hi = [&](nf_solver *S) { return which == 0 ? S->d_chi : which == 2 ? S->d_ehi : S->d_hhi + (size_t)g * S->nlines[2]; };
     auto recv_lo = [&](nf_solver *S) { return which == 2 ? S->d_relo : S->d_rlo; };
@@ -856,11 +895,12 @@ static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int
 {
     PartSegs ps = segs_for(T, counts);
     if (!T->rccl_reduce) {
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 0, T->d_red);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 0, T->d_red, (const double *)nullptr);
     } else {
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 1, T->d_red);
-        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
-        hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, T->stream, op, T->d_red, nq, T->d_cg, out, tol, maxit);
+        // the sums of this rank followed by its error flag: one all-reduce of nq + 1 doubles (CgScalars::err)
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 1, T->d_red, (const double *)T->d_errsrc);
+        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq + 1, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
+        hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, T->stream, op, T->d_red, nq, T->d_cg, out, tol, maxit, 1);
     }
     return NF_OK;
 }
@@ -870,8 +910,9 @@ static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int
 static int team_reduce(nf_team *T, const std::vector<int> &counts, double *red)
 {
     PartSegs ps = segs_for(T, counts);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, 1, T->d_cg, red, 0.0, 0, 1, red);
-    if (T->rccl_reduce) NCCLCHK(g_rccl.AllReduce(red, red, 1, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
+    // red[0] = the sum, red[1] = this rank's error flag: both travel in the one all-reduce (the consumers read red[1], CgLean count < 0)
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, 1, T->d_cg, red, 0.0, 0, 1, red, (const double *)T->d_errsrc);
+    if (T->rccl_reduce) NCCLCHK(g_rccl.AllReduce(red, red, 2, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
     return NF_OK;
 }
 
@@ -930,7 +971,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const int nouter = d == 1 ? S->nz : S->ny;
     // long plain lines of RT0-P0 meshes: two chunks per block, twice the tile width (k_schur_c).  s_long: -1 = from 257 cells per line
     // (where k_schur_s would drop below 32 columns), 0 = never, 1 = whenever the shape allows (tests)
-    if (S->nb == 0 && zmode == 0 && (T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min)) && (size_t)N * sizeof(double) < (1ull << 32)) {   // 32-bit byte offsets inside
+    // (its share of x.y comes in the z.w form only: inside CG it needs the split dot product of team_schur_apply)
+    if (S->nb == 0 && zmode == 0 && (T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min)) && (size_t)N * sizeof(double) < (1ull << 32) &&   // 32-bit byte offsets inside
+        (!(last && partials) || S->zw_dot)) {
         const int NS = (n + 15) / 16;                                // segments of 8 cells per chunk, two chunks
         int TXc = T->opt_s_tx ? T->opt_s_tx : 64;
         while (TXc > 8 && TXc * NS > 1024) TXc >>= 1;
@@ -977,9 +1020,12 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     // undivided meshes beyond the caches (the classic path's sizes): the variant with streaming loads (SF doubles as that flag for !SLAB)
     const bool nt = zmode == 0 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;
     const bool nts = zmode != 0 && zmode != 3 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;   // the same for the z passes of a slab
+    const bool zw = zmode == 0 && S->nb == 0 && S->zw_dot && last && partials;                                              // z.w form of the pass's share of x.y
 #define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (SLABV && NBV == 0 && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (!SLABV && NBV == 0 && zw && SEGV == 8 && nt) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, !SLABV && NBV == 0 && SEGV == 8, false, !SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (!SLABV && NBV == 0 && zw) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false, false, !SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (!SLABV && NBV == 0 && SEGV == 8 && nt) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, !SLABV && NBV == 0 && SEGV == 8>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); } while (0)
 #define NF_S_SEG(DIRV, SLABV, NBV) do { if (SEG == 4) NF_S(4, DIRV, SLABV, NBV); else if (SEG == 8) NF_S(8, DIRV, SLABV, NBV); \
@@ -1051,6 +1097,8 @@ static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double
     return NF_OK;
 }
 
+static bool team_is_single(const nf_team *T) { return T->slabs.size() == 1 && !T->slabs[0]->if_lo && !T->slabs[0]->if_hi; }
+
 // y = S_g x on every local slab.  xs / ys: per-slab device pointers (nphi doubles, layout [p][e]).  With `want_dot` the
 // passes of the last direction leave the block partials of x.y in the team buffer and counts[] receives the number per slab.
 static int team_schur_apply(nf_team *T, int g, const std::vector<const double *> &xs, const std::vector<double *> &ys, bool want_dot,
@@ -1068,6 +1116,12 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
         if (prof) prof_begin(T, 4, &a, &b);
         NFCHK(team_endpoint_phase(T, g, xs, ys, cg, prof ? b : nullptr));
     }
+    // Split dot product (undivided RT0-P0 meshes outside the lean path, i.e. the big ones): every pass leaves the partials of ITS share
+    // of x.y -- the x pass x.(C x + S_x x), the y / z passes T_a sum z_f w_f from their forward sweeps (schur_s_tile, ZW) -- one after
+    // the other in the slab's segment of the partial buffer; the consumer (k_finalize) sums them all.  The last pass then needs x only
+    // for its forward sweep.
+    const bool split = want_dot && dim >= 2 && team_is_single(T) && T->slabs[0]->nb == 0 && !T->slabs[0]->lean.st && T->opt_split_dot;
+    std::vector<int> totals(ns, 0);
     for (int d = 0; d < dim; ++d) {
         const int last = d == dim - 1;
         if (d == 2 && any_if) HIPCHK(hipStreamWaitEvent(T->stream, T->ev_xchg, 0));
@@ -1075,18 +1129,19 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
             const Geom G = make_geom(S);
-            int total = 0;
             {
-                double *part = (want_dot && last) ? T->d_partials + i * T->slab_cap : nullptr;
+                double *part = (want_dot && (last || split)) ? T->d_partials + i * T->slab_cap + totals[i] : nullptr;
                 const ModeArgs ma = mode_args(S, g, d, 0, xs[i], ys[i]);     // mode 0; the kernels derive the others (ModeTab)
                 int np = 0;
-                if (d == 0) NFCHK(launch_x(S, g, ma, G, last, part, cg, &np));
+                S->zw_dot = split;
+                if (d == 0) NFCHK(launch_x(S, g, ma, G, last || split, part, cg, &np));
                 else if (d == 2 && (S->if_lo || S->if_hi)) {
                     NFCHK(launch_s(S, 2, g, ma, G, last, part, cg, &np, 2));
-                } else NFCHK(launch_s(S, d, g, ma, G, last, part, cg, &np, 0));
-                total += np;
+                } else NFCHK(launch_s(S, d, g, ma, G, last || split, part, cg, &np, 0));
+                S->zw_dot = false;
+                if (part) totals[i] += np;
             }
-            if (counts && last) (*counts)[i] = total;
+            if (counts && last) (*counts)[i] = totals[i];
         }
         if (prof) (void)hipEventRecord(b, T->stream);
     }
@@ -1094,7 +1149,6 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
     return NF_OK;
 }
 
-static bool team_is_single(const nf_team *T) { return T->slabs.size() == 1 && !T->slabs[0]->if_lo && !T->slabs[0]->if_hi; }
 
 int nf_schur_apply(nf_handle S, int g, const double *x_dev, double *y_dev)
 {
@@ -1235,7 +1289,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     const CgLean no_lean = { nullptr, nullptr, 0, 0, 0 };
     int rc = NF_OK;
     // lean variant for slab teams (fused, RT0-P0): the endpoint pass of the z lines and k_cg_rupdate consume the all-reduced
-    // totals (d_red[1] = |r|^2, d_red[0] = p.q) and derive beta / alpha and the stop tests themselves: no k_cg_logic launches
+    // totals (d_red[2] = |r|^2, d_red[0] = p.q, each followed by the ranks' error flags) and derive beta / alpha and the stop tests themselves: no k_cg_logic launches
     const bool tlean = fused && T->opt_lean && !team_is_single(T);
     // fused-direction variant on top of the lean one (small / medium meshes): two launches per iteration, see k_apply3
     Fuse3Plan f3;
@@ -1247,10 +1301,29 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         if (S0->dim >= 2 && !S0->d_qy) NFCHK(dalloc(&S0->d_qy, S0->nphi));
         if (S0->dim == 3 && !S0->d_qz) NFCHK(dalloc(&S0->d_qz, S0->nphi));
     }
+    // A local failure on a multi-rank team (a refused launch, a failed HIP call) must not end this rank's part of the schedule: the
+    // other ranks are about to wait in the collectives of this batch.  The rank raises its error flag (it rides in every reduction
+    // that crosses ranks, CgScalars::err), stops launching compute, keeps issuing exactly the collectives the schedule holds, and
+    // returns when the flag has stopped every rank -- at the same iteration everywhere.
+    const bool multi = T->nproc > 1;
+    bool any_if = false; for (auto *S : T->slabs) any_if |= S->if_lo || S->if_hi;
+    auto bad = [&](int code) -> bool {                            // true: leave the loop (single process); false: carry on (poisoned or fine)
+        if (code == NF_OK) return false;
+        if (!multi) { rc = code; return true; }
+        if (!T->poisoned) {
+            T->poisoned = true; T->poison_rc = code; snprintf(T->poison_msg, sizeof T->poison_msg, "%s", nf_last_error());
+            const double one = 1.0;
+            (void)hipMemcpyAsync(T->d_errsrc, &one, sizeof one, hipMemcpyHostToDevice, T->stream);
+            (void)hipStreamSynchronize(T->stream);               // `one` lives on this stack frame; the stream may also have to recover from the failed call
+            (void)hipGetLastError();
+        }
+        return false;
+    };
     while (launched < maxit && rc == NF_OK) {
         int nb = std::min(batch, maxit - launched);
         for (int it = 0; it < nb && rc == NF_OK; ++it) {
             const int index = launched + it;                      // iteration number within this solve
+            const long global_it = T->cg_iter_total++;
             if (f3.ok) {
                 // p lives in a pair of buffers: iteration 0 reads A = d_p as k_cg_init left it; iteration i >= 1 reads the p of
                 // iteration i-1 (A for odd i, B for even i) and writes r + beta p into the other one
@@ -1266,33 +1339,44 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 continue;
             }
             if (lean) T->slabs[0]->lean = CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 };
-            if (tlean) for (auto *S : T->slabs) S->lean_z1 = CgLean{ T->d_cg, T->d_red + 1, -1, index & 1, index == 0 ? 1 : 0 };
-            rc = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
+            if (tlean) for (auto *S : T->slabs) S->lean_z1 = CgLean{ T->d_cg, T->d_red + 2, -1, index & 1, index == 0 ? 1 : 0 };
+            T->xchg_in_apply = 0;
+            int ra = NF_OK;
+            if (multi && T->rank == T->inject_rank && global_it == T->inject_iter)
+                ra = fail(NF_ERR_HIP, "injected failure on rank %d at CG iteration %ld (NEUTFEM_INJECT_FAIL)", T->rank, global_it);
+            else if (!T->poisoned) ra = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
             if (lean) T->slabs[0]->lean = no_lean;
+            if (tlean) for (auto *S : T->slabs) S->lean_z1 = no_lean;
+            if (bad(ra)) break;
+            if (T->poisoned && any_if) {
+                // the interface exchanges this apply still owes its neighbours: one per apply + one per separator sweep (team_endpoint_phase)
+                for (int k = T->xchg_in_apply; k < 1 + T->sep_sweeps; ++k) (void)exchange_planes(T, k == 0 ? 0 : 2, 0, T->comm_stream);
+                (void)hipEventRecord(T->ev_xchg, T->comm_stream); (void)hipStreamWaitEvent(T->stream, T->ev_xchg, 0);
+                for (int i = 0; i < ns; ++i) acnt[i] = 0;
+            }
             if (tlean) {
-                for (auto *S : T->slabs) S->lean_z1 = no_lean;
-                if (rc == NF_OK) rc = team_reduce(T, acnt, T->d_red);
-                if (rc != NF_OK) break;
-                for (int i = 0; i < ns; ++i) {
-                    nf_solver *S = T->slabs[i];
-                    hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap,
-                                       CgLean{ T->d_cg, T->d_red, -1, index & 1, 0 });
-                }
-                rc = team_reduce(T, gcnt, T->d_red + 1);
+                if (bad(team_reduce(T, acnt, T->d_red))) break;   // d_red[0] = p.q, d_red[1] = error flags
+                if (!T->poisoned)
+                    for (int i = 0; i < ns; ++i) {
+                        nf_solver *S = T->slabs[i];
+                        hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap,
+                                           CgLean{ T->d_cg, T->d_red, -1, index & 1, 0 });
+                    }
+                if (bad(team_reduce(T, gcnt, T->d_red + 2))) break;   // d_red[2] = |r|^2, d_red[3] = error flags
                 continue;
             }
-            if (rc == NF_OK && !lean) rc = team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0);
-            if (rc != NF_OK) break;
-            for (int i = 0; i < ns; ++i) {
-                nf_solver *S = T->slabs[i];
-                if (lean) hipLaunchKernelGGL(k_cg_rupdate, dim3(gru), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, row1,
-                                             CgLean{ T->d_cg, T->d_partials, acnt[0], index & 1, 0 });
-                else if (fused) hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap, no_lean);
-                else hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
-            }
+            if (!lean && bad(team_finalize(T, FIN_PAP, acnt, 1, T->d_out, 0.0, 0))) break;
+            if (!T->poisoned)
+                for (int i = 0; i < ns; ++i) {
+                    nf_solver *S = T->slabs[i];
+                    if (lean) hipLaunchKernelGGL(k_cg_rupdate, dim3(gru), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, row1,
+                                                 CgLean{ T->d_cg, T->d_partials, acnt[0], index & 1, 0 });
+                    else if (fused) hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_r, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap, no_lean);
+                    else hipLaunchKernelGGL(k_cg_update, dim3(gcnt[i]), dim3(256), 0, T->stream, x[i], S->d_r, S->d_p, S->d_q, S->nphi, T->d_cg, T->d_partials + i * T->slab_cap);
+                }
             if (lean) continue;
-            rc = team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0);
-            if (fused) continue;
+            if (bad(team_finalize(T, FIN_RR, gcnt, 1, T->d_out, 0.0, 0))) break;
+            if (fused || T->poisoned) continue;
             for (int i = 0; i < ns; ++i) {
                 nf_solver *S = T->slabs[i];
                 hipLaunchKernelGGL(k_cg_pupdate, dim3(gcnt[i]), dim3(256), 0, T->stream, S->d_p, S->d_r, S->nphi, T->d_cg);
@@ -1307,7 +1391,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             if (pub_wait(T, seq, &sc, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
         } else {
             if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
-            if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 1, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
+            if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 2, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
             if (readback(T, T->d_cg, &sc, nullptr, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
         }
         if (sc.done) break;
@@ -1318,6 +1402,13 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     }
     for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = CgFuse{ nullptr, nullptr, nullptr };
     NFCHK(rc);
+    if (T->poisoned) {                                            // the flag has stopped every rank (or maxit did): this rank reports what hit it
+        const int code = T->poison_rc; char msg[256]; snprintf(msg, sizeof msg, "%s", T->poison_msg);
+        T->poisoned = false;
+        (void)hipMemsetAsync(T->d_errsrc, 0, sizeof(double), T->stream);
+        return fail(code, "%s", msg);
+    }
+    if (sc.err == 2) return fail(NF_ERR_REMOTE, "another rank of the team reported an error during the CG solve of group %d; every rank stopped at iteration %d", g, sc.its);
     if (launched == 0) {
         HIPCHK(hipMemcpyAsync(&sc, T->d_cg, sizeof sc, hipMemcpyDeviceToHost, T->stream));
         HIPCHK(hipStreamSynchronize(T->stream));
@@ -1867,7 +1958,7 @@ static int cmfd_step_team(nf_team *T, double keff, int use_diag)
     for (int i = 0; i < ns; ++i) gN[i] = grid_for(T->slabs[i]->N);
     auto reduce_logic = [&](int op, int nq) -> int {
         PartSegs ps = segs_for(T, gN);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, nq, T->d_cg, T->d_red, 0.0, 0, 1, T->d_red);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, nq, T->d_cg, T->d_red, 0.0, 0, 1, T->d_red, (const double *)nullptr);
         if (T->rccl_reduce) NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq, NCCL_DOUBLE, NCCL_SUM, T->comm, st));
         hipLaunchKernelGGL(k_cmfd_logic_tot, dim3(1), dim3(1), 0, st, op, (const double *)T->d_red, sc);
         return NF_OK;
@@ -2338,6 +2429,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         if (it >= 2 && !use_cmfd) ++cheb_it;
         T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
         T->last_outer = it + 1;
+        __atomic_store_n(&T->outers_done, (long)(it + 1), __ATOMIC_RELEASE);
         if (dk < o->tol_keff && dphi < o->tol_flux) break;        // :1799-1802
     }
     HIPCHK(hipStreamSynchronize(T->stream));
@@ -2356,7 +2448,17 @@ int nf_solve_keff(nf_handle S, const nf_keff_opts *o, double *keff, int *n_outer
     if (!S || !o) return fail(NF_ERR_ARG, "nf_solve_keff: bad arguments");
     for (auto *X : S->team->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_solve_keff: call nf_build first");
     HIPCHK(hipSetDevice(S->device));
+    __atomic_store_n(&S->team->outers_done, 0L, __ATOMIC_RELEASE);
     return solve_keff_impl(S->team, o, keff, n_outer);
+}
+
+// Outer iterations the running (or last) nf_solve_keff has completed on the host-driven path.  Safe to call from another thread
+// while the solve runs: a watchdog (bench.py) uses it to tell a slow solve from one whose peers are gone.
+int nf_progress(nf_handle S, long *outers_done)
+{
+    if (!S || !outers_done) return fail(NF_ERR_ARG, "nf_progress: bad arguments");
+    *outers_done = __atomic_load_n(&S->team->outers_done, __ATOMIC_ACQUIRE);
+    return NF_OK;
 }
 
 // ---- SolveAdjoint (src/NeutFEM.cpp:1877-2082) -----------------------------------------------------
@@ -2612,6 +2714,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
+    else if (!strcmp(key, "split_dot")) T->opt_split_dot = value != 0;
     else if (!strcmp(key, "s_long")) T->opt_s_long = value < 0 ? -1 : (value > 0 ? 1 : 0);
     else if (!strcmp(key, "s_long_min")) T->s_long_min = (int)std::max(1L, std::min(1000000L, value));
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;

@@ -28,6 +28,11 @@ struct CgScalars {
     double rr, pAp, alpha, beta, rr_new, tol_sq, rhs_norm, tol;
     int done, its, maxit;
     int pend;      // fused CG only: the x += alpha p of the last FIN_RR has not been applied yet (k_schur_x / k_cg_flush do it)
+    // Error slot.  Every reduction of the solve that crosses ranks carries one extra double next to its sum: a rank that hit a local
+    // error adds a non-zero value there, and a non-finite sum counts as an error too.  The kernel that consumes the reduced value sets
+    // `done` and `err` from it -- on every rank from the same bits, so all ranks leave the solve at the same iteration with an error
+    // instead of one returning early and the others waiting in the next collective.  1 = non-finite sum, 2 = a rank raised its flag.
+    int err;
     // lean CG (CgLean): |r|^2 and the iteration count after the iteration of parity q, so that a kernel whose blocks all read
     // the values of parity q^1 can have its block 0 store those of parity q without a race
     double rr2[2]; int its2[2];
@@ -131,8 +136,14 @@ __device__ __forceinline__ double block_sum(double v, double *sred)
 struct PartSegs { int n; int off[16]; int cnt[16]; };
 enum FinOp { FIN_RHS = 0, FIN_PAP = 1, FIN_RR = 2, FIN_SUM = 3 };
 
-__device__ __forceinline__ void cg_logic(int op, const double *tot, int nq, CgScalars *cg, double *out, double tol, int maxit)
+__device__ __forceinline__ int reduce_err(double total, double flag)       // error slot of an all-reduced sum (CgScalars::err)
 {
+    return flag != 0.0 ? 2 : ((total - total) != 0.0 ? 1 : 0);            // x - x is 0 for every finite x, NaN for inf / NaN
+}
+__device__ __forceinline__ void cg_logic(int op, const double *tot, int nq, CgScalars *cg, double *out, double tol, int maxit, double flag = 0.0)
+{
+    if (op == FIN_RHS) { cg->err = 0; }
+    if (op != FIN_SUM) { const int e = reduce_err(tot[0], flag); if (e) { cg->err = e; cg->done = 1; if (op == FIN_RHS) { cg->rr = tot[0]; cg->its = 0; cg->pend = 0; } return; } }
     if (op == FIN_RHS) {                       // src/solvers.cpp:587-592
         cg->rr = tot[0];
         cg->rhs_norm = sqrt(tot[0]);
@@ -164,10 +175,10 @@ __device__ __forceinline__ void cg_logic(int op, const double *tot, int nq, CgSc
 // reduce_only = 1: write the process-local sums to red[] (an all-reduce over ranks follows, then k_cg_logic)
 __global__ __launch_bounds__(256) void k_finalize(int op, const double *__restrict__ partials, PartSegs segs, long stride,
                                                   int nq, CgScalars *__restrict__ cg, double *__restrict__ out,
-                                                  double tol, int maxit, int reduce_only, double *__restrict__ red)
+                                                  double tol, int maxit, int reduce_only, double *__restrict__ red, const double *__restrict__ errsrc = nullptr)
 {
     __shared__ double sred[4];
-    if (op == FIN_PAP || op == FIN_RR) { if (cg->done) return; }
+    if ((op == FIN_PAP || op == FIN_RR) && !reduce_only) { if (cg->done) return; }
     double tot[4] = { 0, 0, 0, 0 };
     for (int q = 0; q < nq; ++q) {
         double acc = 0.0;
@@ -180,16 +191,17 @@ __global__ __launch_bounds__(256) void k_finalize(int op, const double *__restri
         tot[q] = acc;
     }
     if (threadIdx.x != 0) return;
-    if (reduce_only) { for (int q = 0; q < nq; ++q) red[q] = tot[q]; return; }
+    // reduce_only: the sums go into an all-reduce over ranks, followed by this rank's error flag (errsrc, raised by the host)
+    if (reduce_only) { for (int q = 0; q < nq; ++q) red[q] = tot[q]; if (errsrc) red[nq] = *errsrc; return; }
     cg_logic(op, tot, nq, cg, out, tol, maxit);
 }
 __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgScalars *__restrict__ cg, double *__restrict__ out,
-                           double tol, int maxit)
+                           double tol, int maxit, int with_flag)
 {
     if (op == FIN_PAP || op == FIN_RR) { if (cg->done) return; }
     double tot[4] = { 0, 0, 0, 0 };
     for (int q = 0; q < nq; ++q) tot[q] = red[q];
-    cg_logic(op, tot, nq, cg, out, tol, maxit);
+    cg_logic(op, tot, nq, cg, out, tol, maxit, with_flag ? red[nq] : 0.0);   // red[nq]: the all-reduced error flags of the ranks
 }
 
 // Lean CG (undivided mesh, fused): the two k_finalize launches of an iteration disappear.  The consumer of a reduction sums
@@ -208,6 +220,8 @@ __device__ __forceinline__ double lean_total(const CgLean &lean, double *sred)
 {
     return lean.count < 0 ? lean.partials[0] : strided_total(lean.partials, lean.count, sred);
 }
+// count < 0: partials[1] is the error slot that travelled with the total (sum of the ranks' flags)
+__device__ __forceinline__ int lean_err(const CgLean &lean, double total) { return reduce_err(total, lean.count < 0 ? lean.partials[1] : 0.0); }
 __device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred)   // blocks of >= 256 threads; result in every thread
 {
     // summed by the first 256 threads only, so that blocks of any size (and k_finalize) produce the same bits: the other
@@ -236,6 +250,12 @@ __device__ __forceinline__ bool lean_rr_step(const CgLean &lean, const LeanPre &
     CgScalars *st = lean.st;
     const int q = lean.par;
     const double rr_new = lean_total(lean, sred);
+    const int e = lean_err(lean, rr_new);
+    if (e) {                                                     // every block (and every rank) takes this branch from the same bits
+        if (writer) { st->rr_new = rr_new; st->rr = rr_new; st->err = e; st->done = 1; }
+        *beta_out = 0.0;
+        return true;
+    }
     const double rr_old = pre.rr_old;
     const int its_new = pre.its_old + 1;
     const bool conv = rr_new < pre.tol_sq;
@@ -797,7 +817,11 @@ struct SlabArgs {
 // r + beta x, formed on the fly (see CgFuse).  Returns the thread's share of x.y.
 // SF (slab variants): the instantiation that can carry the fused CG update (r and x_sol of the cells in registers: 160 instead of
 // 128 VGPRs); the accumulation / emit passes use the one without
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid>   // NTS: streaming loads in a slab variant
+// ZW (plain RT0-P0 lines): the pass's share of x.y is not summed as x_i y_i over the cells -- x.(S_d x) = T_a t^T A^-1 t with
+// A = L D L^T is T_a sum_faces z_f^2 / d_f = T_a sum z_f w_f, and both factors are at hand in the forward sweep.  The x pass then
+// contributes x.(C x + S_x x) and the consumer adds the three sets of partials: the backward half of a y / z pass needs no x at all
+// (eight doubles fewer live through the scans, and the chunked long-line pass has nothing to re-read for its parked chunk).
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid, bool ZW = false>   // NTS: streaming loads in a slab variant
 __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                                                unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
@@ -976,8 +1000,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     else { z = sZ0[ixl]; for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl]; }
     const double zin = z;
     double w[SEG];
+    double zw = (ZW && c0 == 0) ? zin * (zin * dinv_s) : 0.0;    // the line's first face (lanes outside the mesh hold zeros)
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { const double ti = NB == 0 ? xv[i] - xv[i + 1] : t[NB > 0 ? i : 0]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; }
+    for (int i = 0; i < SEG; ++i) { const double ti = NB == 0 ? xv[i] - xv[i + 1] : t[NB > 0 ? i : 0]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; if (ZW) zw += z * w[i]; }
+    if (ZW) asm volatile("" : "+v"(zw));                         // summed here, not sunk to the end of the kernel (which would keep every z alive)
     double Q = 1.0, lu = 0.0;
 #pragma unroll
     for (int i = SEG - 1; i >= 0; --i) { lu = w[i] - Lv[i + 1] * lu; Q = -Lv[i + 1] * Q; }
@@ -1026,7 +1052,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
         for (int i = 0; i < SEG; ++i) {
             const double lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
             const bool in = valid && c0 + i < n;                 // a select, not a branch (slab chains: xv of the cell behind the chain end is the edge cell)
-            yo[i] = yo[i] + ma.Ta * (w[i] - lo); dot += in ? xv[i] * yo[i] : 0.0;
+            yo[i] = yo[i] + ma.Ta * (w[i] - lo); if (!ZW) dot += in ? xv[i] * yo[i] : 0.0;
             if (NB > 0) {
                 const double v = ma.Gc[0] * x1[i] * ma.iM[0] * icv[i] - (ma.eL[0] * lo + ma.eR[0] * w[i]);
                 y1o[i] = y1o[i] + ma.Ta * ma.Gc[0] * v; dot += in ? x1[i] * y1o[i] : 0.0;
@@ -1047,6 +1073,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             }
         }
     }
+    if (ZW) dot = ma.Ta * zw;
     if (SLAB && sa.mode == 3) {                                 // emit J_z = -u on every face of the local line (+ the z bubbles for RT1+)
         if (valid) {
             const long nxy = sl;                                 // z lines: stride between planes = nx * ny
@@ -1142,7 +1169,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 
 // Slab variants keep r and x_sol of their cells in registers next to x, L, 1/d (loads first, see schur_s_tile): blocks of at most 512
 // threads, so that the register budget is 256 per thread (the host picks TX accordingly)
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false>
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, bool ZW = false>
 __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4)) : 1) void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                           int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz, CgLean lean)
@@ -1167,7 +1194,8 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
         const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
     }
-    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF, NTS>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
+    static_assert(!ZW || (!SLAB && NB == 0), "the z.w form of the dot product is for plain RT0-P0 lines");
+    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF, NTS, NoMid, ZW>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
                                                             (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
     if (SLAB && sa.mode == 3) return;
     if (last && partials) {
@@ -1184,8 +1212,8 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
 //   forward sweep of chunk 0 (its face values w and its factors L are parked in LDS: 2 x 64 KB for 1024 threads), forward and
 //   backward sweep of chunk 1 out of registers (exactly k_schur_s's body), backward sweep of chunk 0 out of LDS.
 // A chunk boundary is a segment boundary like any other -- the same affine-map summaries, composed serially per thread; the z
-// (u) value that crosses it is handed over through sC.  Every global array is still read once and written once per pass; only the
-// p.q share of chunk 0 (last pass of an apply inside CG) re-reads x, which the parked arrays leave no LDS for.
+// (u) value that crosses it is handed over through sC.  Every global array is read once and written once per pass.  The pass's
+// share of x.y is formed in the forward sweeps as T_a sum z_f w_f (see schur_s_tile, ZW), so the backward half needs no x.
 // LDS (doubles): sA, sB [NS TX] (forward and backward summaries in turn), sC, sL1 [TX], 16 of reduction scratch, pW, pL [CH TX], pZ [NS TX].
 // Per cell the same expressions as k_schur_s (the value crossing the chunk boundary is the swept one, not a composed summary:
 // the two kernels agree to rounding, not bitwise).
@@ -1224,7 +1252,7 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
     const long lineid = (long)by * nx + ix;
     const bool need_dot = last && partials;
     double xv[SEG + 1], Lv[SEG + 1], Rv[SEG], w[SEG], yo[SEG];
-    double zin = 0.0, dinv_s = 0.0, zc = 0.0;
+    double zin = 0.0, dinv_s = 0.0, zc = 0.0, dot = 0.0;
     // ---- forward sweeps, chunk 0 then chunk 1
     for (int ch = 0; ch < 2; ++ch) {
         const int c0 = ch * CH + seg * SEG;
@@ -1253,8 +1281,10 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
         double z = sC[ixl];
         for (int s = 0; s < seg; ++s) z = sA[s * TX + ixl] * z + sB[s * TX + ixl];
         zin = z; dinv_s = ds;
+        if (c0 == 0) dot = zin * (zin * ds);                     // the line's first face
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) { const double ti = xv[i] - xv[i + 1]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; }
+        for (int i = 0; i < SEG; ++i) { const double ti = xv[i] - xv[i + 1]; z = ti - Lv[i] * z; w[i] = z * Rv[i]; dot += z * w[i]; }
+        asm volatile("" : "+v"(dot));                            // summed HERE: left alone, the optimiser sinks the products to the kernel's end and keeps every z and w of both chunks alive (in scratch) until then
         zc = z;
         if (ch == 0 && act) {
 #pragma unroll
@@ -1263,16 +1293,17 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
         }
     }
     // ---- backward sweeps and output, chunk 1 (still in registers) then chunk 0 (from LDS)
-    double dot = 0.0, ucar = 0.0;
+    double ucar = 0.0;
     for (int ch = 1; ch >= 0; --ch) {
         const int c0 = ch * CH + seg * SEG;
         const unsigned o0 = ob + (unsigned)c0 * slb;
         if (ch == 0) {
+            // (the index is made opaque: otherwise the optimiser forwards the values this thread parked itself, i.e. keeps all of chunk 0
+            // alive across chunk 1 -- in scratch memory, since the registers are full: 100 B per lane of spills instead of LDS reads)
+            int pbase = seg * SEG * TX + ixl;
+            asm volatile("" : "+v"(pbase));
 #pragma unroll
-            for (int i = 0; i < SEG; ++i) {
-                w[i] = pW[(seg * SEG + i) * TX + ixl]; Lv[i] = pL[(seg * SEG + i) * TX + ixl];
-                xv[i] = (need_dot && valid && c0 + i < n) ? ldo<NT>(x, o0 + (unsigned)i * slb) : 0.0;
-            }
+            for (int i = 0; i < SEG; ++i) { w[i] = pW[pbase + i * TX]; Lv[i] = pL[pbase + i * TX]; }
             Lv[SEG] = seg < NS - 1 ? pL[(seg + 1) * SEG * TX + ixl] : sL1[ixl];   // written before the barriers in between
             zin = pZ[si];
             dinv_s = 0.0;
@@ -1296,15 +1327,14 @@ __global__ __launch_bounds__(1024, 1) void k_schur_c(const double *__restrict__ 
 #pragma unroll
         for (int i = 0; i < SEG; ++i) {                          // values first, branch-free, then the stores (see schur_s_tile)
             const double lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
-            const bool in = valid && c0 + i < n;
-            yo[i] = yo[i] + Ta * (w[i] - lo); dot += in ? xv[i] * yo[i] : 0.0;
+            yo[i] = yo[i] + Ta * (w[i] - lo);
         }
 #pragma unroll
         for (int i = 0; i < SEG; ++i)
             if (valid && c0 + i < n) *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + (o0 + (unsigned)i * slb)) = yo[i];
     }
     if (need_dot) {
-        const double s = block_sum(dot, sred);
+        const double s = block_sum(Ta * dot, sred);
         if (threadIdx.x == 0) partials[(long)by * gridDim.x + bx] = s;
     }
 }
@@ -1467,6 +1497,8 @@ __global__ __launch_bounds__(256) void k_cg_rupdate(double *__restrict__ r, cons
     double alpha;
     if (lean.st) {                                              // lean CG: this kernel consumes the p.q partials (FIN_PAP)
         const double pq = lean_total(lean, sred);
+        const int e = lean_err(lean, pq);
+        if (e) { if (blockIdx.x == 0 && threadIdx.x == 0) { lean.st->pAp = pq; lean.st->err = e; lean.st->done = 1; } return; }
         const bool brk = fabs(pq) < 1e-30;
         alpha = brk ? 0.0 : lean.st->rr2[lean.par] / pq;
         if (blockIdx.x == 0 && threadIdx.x == 0) { lean.st->pAp = pq; lean.st->pend = 0; if (brk) lean.st->done = 1; else lean.st->alpha = alpha; }

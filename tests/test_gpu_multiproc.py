@@ -31,8 +31,9 @@ def _env():
     return e
 
 
-def _run_ranks(world, args, tmp_path, timeout=200, env=None):
-    """start `world` workers, fail fast (with every rank's output) if one exits non-zero or the run exceeds `timeout` s"""
+def _run_ranks(world, args, tmp_path, timeout=200, env=None, wait_all=False):
+    """start `world` workers, fail fast (with every rank's output) if one exits non-zero or the run exceeds `timeout` s.
+    wait_all: let every rank end by itself (no kill on the first failure) -- the point of the test is that they all do"""
     import time
     port = str(_free_port())
     logs = [open(str(tmp_path / f"rank{r}.log"), "w+") for r in range(world)]
@@ -40,7 +41,7 @@ def _run_ranks(world, args, tmp_path, timeout=200, env=None):
                               env=env or _env(), stdout=logs[r], stderr=subprocess.STDOUT) for r in range(world)]
     t0 = time.time(); bad = None
     while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs): bad = "a rank failed"; break
+        if not wait_all and any(p.poll() not in (None, 0) for p in procs): bad = "a rank failed"; break
         if time.time() - t0 > timeout: bad = f"timed out after {timeout} s"; break
         time.sleep(0.2)
     if bad is None and any(p.returncode != 0 for p in procs): bad = "a rank failed"
@@ -102,6 +103,26 @@ def test_indivisible_coarse_factors_are_refused_by_every_rank(tmp_path):
     bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, 0, 0, 100], tmp_path, timeout=120)
     assert bad == "a rank failed", (bad, logs)
     assert logs.count("do not divide") >= 3, logs
+
+
+def test_failing_rank_stops_every_rank_instead_of_hanging_them(tmp_path):
+    """a rank-local error inside a solve used to return on that rank only -- the others then waited in
+    ncclAllReduce until somebody killed the job.  NEUTFEM_INJECT_FAIL=1:40 makes rank 1 of 3 fail (as a refused launch would) at its
+    41st CG iteration.  Expected: rank 1 raises its error flag in the all-reduces that exist anyway, keeps the collective schedule
+    going, and ALL THREE ranks leave the solve at the same iteration -- rank 1 with its own error, ranks 0 and 2 with NF_ERR_REMOTE --
+    within seconds, by themselves."""
+    import time
+    e = _env(); e["NEUTFEM_INJECT_FAIL"] = "1:40"; e["NEUTFEM_COMM_TIMEOUT_S"] = "60"
+    t0 = time.time()
+    bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, 0, 16], tmp_path, timeout=150, env=e, wait_all=True)
+    assert bad == "a rank failed", (bad, logs)                     # i.e. not "timed out": every rank ended by itself
+    assert time.time() - t0 < 120, logs
+    per = logs.split("--- rank ")[1:]
+    assert len(per) == 3 and all("(rc=0)" not in p.splitlines()[0] for p in per), logs      # nobody pretends to have succeeded
+    assert "injected failure on rank 1" in per[1], logs
+    assert "another rank of the team reported an error" in per[0] and "another rank of the team reported an error" in per[2], logs
+    its = [int(p.split("every rank stopped at iteration ")[1].split()[0].rstrip(".,;)")) for p in (per[0], per[2])]
+    assert its[0] == its[1], logs                                 # the same iteration on both healthy ranks
 
 
 def test_bench_two_ranks_on_one_gpu():
