@@ -139,6 +139,7 @@ struct nf_team {
     long lean_max_cells = 4L << 20;                     // above that the redundant partial sums of 16 k x-pass blocks cost what the two tiny kernels cost
     OuterState *d_ost = nullptr; double *d_hist = nullptr; int hist_cap = 0;   // device-resident outer loop (diagonal path)
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
+    int opt_x_p2 = 0;                                     // x pass inside CG: two load phases (k_schur_x P2); measured no gain, off
     int opt_split_dot = 1;                                // big undivided RT0-P0 meshes: per-pass shares of p.q (team_schur_apply)
     int opt_s_long = -1, s_long_min = 256;                // chunked long-line pass (k_schur_c): -1 auto (lines longer than s_long_min), 0 off, 1 always
     size_t lds_limit = 160 * 1024;                        // dynamic LDS a block may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock at team creation)
@@ -916,6 +917,19 @@ static int team_reduce(nf_team *T, const std::vector<int> &counts, double *red)
     return NF_OK;
 }
 
+// Opt a kernel in to `lds` bytes of dynamic LDS (above the 64 KiB a launch gets by default).  Asked once per kernel and size class,
+// not on every solve; a refusal (a device or driver with less LDS than planned for) is not an error of the solve: the caller steps
+// back to the host-driven path.
+static bool lds_opt_in(const void *fn, size_t lds)
+{
+    if (lds <= 64 * 1024) return true;
+    static std::map<const void *, size_t> granted;
+    auto it = granted.find(fn);
+    if (it != granted.end() && it->second >= lds) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+    granted[fn] = lds;
+    return true;
+}
 // ---- Schur apply -----------------------------------------------------------------------------
 template <int NCH, int NB>
 static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int lpl_log2, int first, int last,
@@ -929,7 +943,12 @@ static void launch_x_t(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, i
     const ModeTab mt = mode_tab(S, 0);
     const dim3 gr(grid, (unsigned)mt.n);                          // all transverse modes in one launch
     const bool nt = NB == 0 && vec && S->team->opt_nt_loads && N > S->team->nt_min_cells;   // streaming loads beyond the caches (per slab on teams)
-    if (nt) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB, NB == 0>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2,
+    // inside CG: two load phases (schur_x_task, P2): 116 instead of 140 VGPRs at four chunks per lane, four waves per SIMD instead of
+    // three -- and no faster (512^3: 1548 vs 1529 us, 256^3: 185.9 vs 186.3; profiles/r03_e_ab_cg.txt).  Kept as an option, off.
+    const bool p2 = NB == 0 && NCH >= 2 && fz.p && S->team->opt_x_p2 == 1;
+    if (nt && p2) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB, NB == 0, NB == 0 && (NCH >= 2)>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2,
+                               first | ((S->team->opt_xcd >= 0 && (S->team->opt_xcd & 4)) ? 2 : 0), last, partials, cg, fz, S->lean);
+    else if (nt) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB, NB == 0>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2,
                                first | ((S->team->opt_xcd >= 0 && (S->team->opt_xcd & 4)) ? 2 : 0), last, partials, cg, fz, S->lean);
     else if (vec) hipLaunchKernelGGL((k_schur_x<2, NCH, true, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
     else hipLaunchKernelGGL((k_schur_x<2, NCH, false, NB>), gr, dim3(256), 0, st, ma, mt, G, L, DR, D0, S->nx, S->ny, S->nlines[0], lpl_log2, first, last, partials, cg, fz, S->lean);
@@ -960,6 +979,25 @@ static int launch_x(nf_solver *S, int g, const ModeArgs &ma, const Geom &G, int 
     return launch_x_nb<2>(S, g, ma, G, last, partials, cg, nparts);
 }
 
+// Does direction d (1 = y, 2 = z) of this mesh take the chunked long-line kernel (k_schur_c)?  Plain lines of RT0-P0 meshes beyond
+// s_long_min cells (s_long: -1 = from 257 cells per line, where k_schur_s would drop below 32 columns; 0 = never; 1 = whenever the
+// shape allows), one group's array below 4 GiB (32-bit byte offsets inside), at most 1024 threads and the device's LDS.
+struct ChunkPlan { bool ok = false; int NS = 0, TX = 0; size_t lds = 0; };
+static ChunkPlan chunk_plan(const nf_solver *S, int d)
+{
+    ChunkPlan P; const nf_team *T = S->team;
+    const int n = d == 1 ? S->ny : S->nz;
+    if (S->nb != 0 || d < 1 || d >= S->dim || (d == 2 && (S->if_lo || S->if_hi))) return P;
+    if (!(T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min)) || (size_t)S->N * sizeof(double) >= (1ull << 32)) return P;
+    P.NS = (n + 15) / 16;                                        // segments of 8 cells per chunk, two chunks
+    P.TX = T->opt_s_tx ? T->opt_s_tx : 64;
+    while (P.TX > 8 && P.TX * P.NS > 1024) P.TX >>= 1;
+    while (P.TX > 8 && P.TX / 2 >= S->nx) P.TX >>= 1;
+    P.lds = (size_t)(3 * P.TX * P.NS + 2 * P.TX + 16 + 2 * 8 * P.NS * P.TX) * sizeof(double);
+    P.ok = P.TX * P.NS <= 1024 && P.lds <= T->lds_limit;
+    return P;
+}
+
 // zmode: 0 = plain line kernel (y lines, or z lines of an undivided mesh); 1 / 2 = slab chain passes (z lines)
 static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts, int zmode)
 {
@@ -969,28 +1007,22 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const long nxy = (long)S->nx * S->ny;
     const long sl = d == 1 ? S->nx : nxy, ostride = d == 1 ? nxy : S->nx;
     const int nouter = d == 1 ? S->nz : S->ny;
-    // long plain lines of RT0-P0 meshes: two chunks per block, twice the tile width (k_schur_c).  s_long: -1 = from 257 cells per line
-    // (where k_schur_s would drop below 32 columns), 0 = never, 1 = whenever the shape allows (tests)
-    // (its share of x.y comes in the z.w form only: inside CG it needs the split dot product of team_schur_apply)
-    if (S->nb == 0 && zmode == 0 && (T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min)) && (size_t)N * sizeof(double) < (1ull << 32) &&   // 32-bit byte offsets inside
-        (!(last && partials) || S->zw_dot)) {
-        const int NS = (n + 15) / 16;                                // segments of 8 cells per chunk, two chunks
-        int TXc = T->opt_s_tx ? T->opt_s_tx : 64;
-        while (TXc > 8 && TXc * NS > 1024) TXc >>= 1;
-        while (TXc > 8 && TXc / 2 >= S->nx) TXc >>= 1;
-        const size_t ldsc = (size_t)(3 * TXc * NS + 2 * TXc + 16 + 2 * 8 * NS * TXc) * sizeof(double);
-        if (TXc * NS <= 1024 && ldsc <= T->lds_limit) {
+    // long plain lines of RT0-P0 meshes: two chunks per block, twice the tile width (k_schur_c).  Its share of x.y comes in the z.w
+    // form only: inside CG it needs the split dot product of team_schur_apply
+    const ChunkPlan cp = zmode == 0 ? chunk_plan(S, d) : ChunkPlan();
+    if (cp.ok && (!(last && partials) || S->zw_dot)) {
+        const int NS = cp.NS, TXc = cp.TX; const size_t ldsc = cp.lds;
+        {
             dim3 grid((unsigned)((S->nx + TXc - 1) / TXc), (unsigned)nouter), block((unsigned)((TXc * NS + 63) / 64 * 64));
-            if (nparts) *nparts = (int)(grid.x * grid.y);
             const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
             const bool nt = T->opt_nt_loads && S->N > T->nt_min_cells;
             const int xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : (d == 1 && nt);
-#define NF_C(DIRV, NTV) do { static bool attr_set = false; \
-            if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_schur_c<DIRV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T->lds_limit)); attr_set = true; } \
-            hipLaunchKernelGGL((k_schur_c<DIRV, NTV>), grid, block, ldsc, T->stream, ma.x[0], ma.y[0], ma.Ta, L, DR, D0, n, sl, ostride, S->nx, TXc, NS, last, partials, cg, xcd); } while (0)
+            bool launched = false;                                    // false: the device refused the LDS -> the one-chunk kernel below
+#define NF_C(DIRV, NTV) do { if (lds_opt_in((const void *)k_schur_c<DIRV, NTV>, ldsc)) { launched = true; \
+            hipLaunchKernelGGL((k_schur_c<DIRV, NTV>), grid, block, ldsc, T->stream, ma.x[0], ma.y[0], ma.Ta, L, DR, D0, n, sl, ostride, S->nx, TXc, NS, last, partials, cg, xcd); } } while (0)
             if (d == 1) { if (nt) NF_C(1, true); else NF_C(1, false); } else { if (nt) NF_C(2, true); else NF_C(2, false); }
 #undef NF_C
-            return NF_OK;
+            if (launched) { if (nparts) *nparts = (int)(grid.x * grid.y); return NF_OK; }
         }
     }
     // 8-cell segments up to 1024 cells per line (16 / 32 cells spill to scratch: 1.4x slower even though TX drops to 8 at 1024)
@@ -1120,7 +1152,11 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
     // of x.y -- the x pass x.(C x + S_x x), the y / z passes T_a sum z_f w_f from their forward sweeps (schur_s_tile, ZW) -- one after
     // the other in the slab's segment of the partial buffer; the consumer (k_finalize) sums them all.  The last pass then needs x only
     // for its forward sweep.
-    const bool split = want_dot && dim >= 2 && team_is_single(T) && T->slabs[0]->nb == 0 && !T->slabs[0]->lean.st && T->opt_split_dot;
+    // Taken where a chunked long-line pass runs (it has no x left when its parked chunk comes back) or on request (split_dot = 2: tests);
+    // elsewhere the last pass sums x_i y_i with x still in its registers, which is cheaper than three sets of partials (256^3: 504 vs
+    // 531 us per CG iteration, profiles/r03_e_ab_cg.txt).
+    bool split = want_dot && dim >= 2 && team_is_single(T) && T->slabs[0]->nb == 0 && !T->slabs[0]->lean.st && T->opt_split_dot;
+    if (split && T->opt_split_dot < 2) { split = false; for (int d = 1; d < dim; ++d) split |= chunk_plan(T->slabs[0], d).ok; }
     std::vector<int> totals(ns, 0);
     for (int d = 0; d < dim; ++d) {
         const int last = d == dim - 1;
@@ -1844,7 +1880,8 @@ int nf_initialize_cmfd(nf_handle S)
     HIPCHK(hipStreamSynchronize(S->team->stream));
     return NF_OK;
 }
-int nf_set_cmfd_relaxation(nf_handle S, double omega) { if (!S) return fail(NF_ERR_ARG, "null handle"); S->cmfd_relax = omega; return NF_OK; }
+// team-wide: every slab of the handle's team applies the same omega in k_cmfd_correct (on a multi-rank run every rank must set the same value)
+int nf_set_cmfd_relaxation(nf_handle S, double omega) { if (!S) return fail(NF_ERR_ARG, "null handle"); for (auto *X : S->team->slabs) X->cmfd_relax = omega; return NF_OK; }
 int nf_get_cmfd_coefficients(nf_handle S, int g, int dir, double *dtilde_host, double *dhat_host)
 {
     if (!S || g < 0 || g >= S->ng || dir < 0 || dir > 2) return fail(NF_ERR_ARG, "nf_get_cmfd_coefficients: bad arguments");
@@ -2166,6 +2203,7 @@ static bool resident_serial_fits(const nf_team *T, const nf_solver *S)
     const long PC = (Np + 63) & ~63L, NPp = PC * S->nloc;
     return NPp <= 5120 && n_modes(S) <= 9 && S->nloc <= 27 && 64 + 16 + 176 + (1 + S->dim) * NPp + 2L * S->dim * PC + 3 * lines <= cap;
 }
+static const int NF_RESIDENT_UNAVAILABLE = 1;                     // positive: not an error code of the C ABI
 static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, const double *ca, const double *cbv, double sigma,
                                double cg_tol, int cg_max, double *keff_out)
 {
@@ -2215,7 +2253,7 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
         if (Np <= pitch && need <= cap) {
             serial = true;
             const size_t lds = (size_t)need * sizeof(double);
-#define NF_RES_SERIAL(P) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<false, 0, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+#define NF_RES_SERIAL(P) do { if (!lds_opt_in((const void *)k_resident_keff<false, 0, P>, lds)) return NF_RESIDENT_UNAVAILABLE; \
             hipLaunchKernelGGL((k_resident_keff<false, 0, P>), dim3(1), dim3(B), lds, st, A); } while (0)
             if (pitch == 1536) NF_RES_SERIAL(1536); else NF_RES_SERIAL(2560);
 #undef NF_RES_SERIAL
@@ -2246,7 +2284,7 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
                     for (int l = 0; l < S->nb; ++l) A.diagc[A.mom[d][m][l + 1]][d] = Ta * c.Gc[l] * c.Gc[l] * c.iM[l];
                 }
             const size_t lds = (size_t)need * sizeof(double);
-#define NF_RES_HI(NBV) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<false, NBV, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+#define NF_RES_HI(NBV) do { if (!lds_opt_in((const void *)k_resident_keff<false, NBV, -1>, lds)) return NF_RESIDENT_UNAVAILABLE; \
             hipLaunchKernelGGL((k_resident_keff<false, NBV, -1>), dim3(1), dim3(B), lds, st, A); } while (0)
             if (S->nb == 1) NF_RES_HI(1); else NF_RES_HI(2);
 #undef NF_RES_HI
@@ -2267,7 +2305,7 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
         }
     }
     const size_t lds = (size_t)used * sizeof(double);
-#define NF_RES(VECV, NBV) do { if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_resident_keff<VECV, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+#define NF_RES(VECV, NBV) do { if (!lds_opt_in((const void *)k_resident_keff<VECV, NBV>, lds)) return NF_RESIDENT_UNAVAILABLE; \
         hipLaunchKernelGGL((k_resident_keff<VECV, NBV>), dim3(1), dim3(B), lds, st, A); } while (0)
     const bool vec = S->nx % 2 == 0;
     if (S->nb == 0) { if (vec) NF_RES(true, 0); else NF_RES(false, 0); }
@@ -2353,13 +2391,18 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         ResidentArgs probe;
         if (single && !use_diag && !use_cmfd && !direct && !T->rccl_reduce && T->opt_resident && o->max_outer > 0 &&
             ((S0->nphi <= T->resident_max_dofs && resident_plan(S0, &probe)) || (S0->nphi <= T->resident_serial_max_dofs && resident_serial_fits(T, S0)))) {
+            const bool prof_req = T->profile;
             T->last_path = 2; T->profile = false;
-            NFCHK(solve_keff_resident(T, o, keff, ca, cbv, sigma, cg_tol, cg_max, &keff));
-            S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = false; S0->jz_valid = false;
-            T->has_valid_keff = 1; T->last_keff = keff;
-            if (keff_out) *keff_out = keff;
-            if (n_outer) *n_outer = T->last_outer;
-            return NF_OK;
+            const int rr = solve_keff_resident(T, o, keff, ca, cbv, sigma, cg_tol, cg_max, &keff);
+            if (rr != NF_RESIDENT_UNAVAILABLE) {
+                NFCHK(rr);
+                S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = false; S0->jz_valid = false;
+                T->has_valid_keff = 1; T->last_keff = keff;
+                if (keff_out) *keff_out = keff;
+                if (n_outer) *n_outer = T->last_outer;
+                return NF_OK;
+            }
+            T->last_path = 0; T->profile = prof_req;              // the device refused the LDS the resident kernel plans with: host-driven path
         }
     }
     ScatterArgs sa; sa.ng = ng;
@@ -2714,7 +2757,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
-    else if (!strcmp(key, "split_dot")) T->opt_split_dot = value != 0;
+    else if (!strcmp(key, "split_dot")) T->opt_split_dot = (int)std::max(0L, std::min(2L, value));   // 0 never, 1 where a chunked pass runs, 2 always (big undivided RT0-P0 meshes)
+    else if (!strcmp(key, "x_two_phase")) T->opt_x_p2 = value < 0 ? -1 : (value > 0 ? 1 : 0);
     else if (!strcmp(key, "s_long")) T->opt_s_long = value < 0 ? -1 : (value > 0 ? 1 : 0);
     else if (!strcmp(key, "s_long_min")) T->s_long_min = (int)std::max(1L, std::min(1000000L, value));
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;

@@ -116,6 +116,23 @@ __device__ __forceinline__ void scan_maps_down(double &A, double &B, int LPL, in
     }
 }
 
+// thread t of the first 256 sums p[t], p[t + 256], ... in that order; the loads go out eight at a time (one memory round trip per
+// eight terms instead of one per term: with 82 k partials -- split dot product at 512^3 -- the serial version took ~130 us)
+__device__ __forceinline__ double strided_sum256(const double *__restrict__ p, int cnt)
+{
+    double s = 0.0;
+    int i = threadIdx.x;
+    if (threadIdx.x >= 256) return 0.0;
+    for (; i + 7 * 256 < cnt; i += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[i + j * 256];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; i < cnt; i += 256) s += p[i];
+    return s;
+}
 // fixed-order block sum; result valid in thread 0.  sred: >= blockDim/64 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *sred)
 {
@@ -183,8 +200,7 @@ __global__ __launch_bounds__(256) void k_finalize(int op, const double *__restri
     for (int q = 0; q < nq; ++q) {
         double acc = 0.0;
         for (int sgi = 0; sgi < segs.n; ++sgi) {
-            double s = 0.0;
-            for (int i = threadIdx.x; i < segs.cnt[sgi]; i += 256) s += partials[q * stride + segs.off[sgi] + i];
+            double s = strided_sum256(partials + q * stride + segs.off[sgi], segs.cnt[sgi]);
             s = block_sum(s, sred);
             acc += s;
         }
@@ -226,8 +242,7 @@ __device__ __forceinline__ double strided_total(const double *p, int cnt, double
 {
     // summed by the first 256 threads only, so that blocks of any size (and k_finalize) produce the same bits: the other
     // threads add exact zeros
-    double s = 0.0;
-    if (threadIdx.x < 256) for (int i = threadIdx.x; i < cnt; i += 256) s += p[i];
+    double s = strided_sum256(p, cnt);
     s = block_sum(s, sred);
     if (threadIdx.x == 0) sred[0] = s;
     __syncthreads();
@@ -604,7 +619,10 @@ struct CgFuse { double *p; const double *r; double *xsol; double *pout; };
 // DPPS: cross-lane traffic of the scans through data-parallel primitives (VALU) instead of ds_bpermute (LDS crossbar).  That halves
 // the latency of a lone wave-task (resident kernel: 14.2 k -> 10.9 k cycles per x pass) but costs VALU issue slots: with many waves
 // per SIMD the crossbar version is faster (fused-direction launch at 128^3: 76.8 vs 82.9 us per CG iteration on the same box).
-template <int K, int NCH, bool VEC, int NB, class Mid = NoMid, bool DPPS = false, bool NT = false>
+// P2 (long lines inside CG, NCH >= 4): two load phases instead of one -- p, r, x_sol first (the deferred CG update consumes r and
+// x_sol at once), then L, 1/d and the C diagonal.  Everything in flight at once costs 140 VGPRs at four chunks per lane (three waves
+// per SIMD); in two phases the peak is the sweep's own working set.
+template <int K, int NCH, bool VEC, int NB, class Mid = NoMid, bool DPPS = false, bool NT = false, bool P2 = false>
 __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2, int first,
                                                long task, int lane, bool active, bool fuse, double f_alpha, double f_beta, const CgFuse &fz, Mid mid = Mid())
@@ -624,12 +642,14 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (ch * LPL + li) * K;
         const bool ok = lv && c0 < nx, ok2 = lv && c0 + 1 < nx;
-        ld2<NT>(L, base + c0, ok, VEC, Ls[ch][0], Ls[ch][1], ok2);
-        ld2<NT>(DR, base + c0, ok, VEC, Rs[ch][0], Rs[ch][1], ok2);
+        if (!P2) {
+            ld2<NT>(L, base + c0, ok, VEC, Ls[ch][0], Ls[ch][1], ok2);
+            ld2<NT>(DR, base + c0, ok, VEC, Rs[ch][0], Rs[ch][1], ok2);
+        }
 #pragma unroll
         for (int q = 0; q <= NB; ++q) {
             ld2<NT>(ma.x[q], base + c0, ok, VEC, xm[q][ch][0], xm[q][ch][1], ok2);
-            ld2<NT>(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
+            if (!P2) ld2<NT>(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
             if (fuse) {                                          // ma.x[q] points into p: the same offset addresses r and x_sol
                 const long mo = (ma.x[q] - fz.p) + base + c0;
                 ld2<NT>(fz.r, mo, ok, VEC, rq[q][ch][0], rq[q][ch][1], ok2);
@@ -671,6 +691,17 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
                 for (int l = 0; l < NB; ++l) { const double gx = ma.Gc[l] * xm[l + 1][ch][j]; pl += ma.eL[l] * gx; pr += ma.eR[l] * gx; }
             }
             xL[ch][j] = xm[0][ch][j] + pl; xR[ch][j] = xm[0][ch][j] - pr;
+        }
+    }
+    if (P2) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {                       // second load phase: what the sweeps and the output need
+            const int c0 = (ch * LPL + li) * K;
+            const bool ok = lv && c0 < nx, ok2 = lv && c0 + 1 < nx;
+            ld2<NT>(L, base + c0, ok, VEC, Ls[ch][0], Ls[ch][1], ok2);
+            ld2<NT>(DR, base + c0, ok, VEC, Rs[ch][0], Rs[ch][1], ok2);
+#pragma unroll
+            for (int q = 0; q <= NB; ++q) ld2<NT>(first ? ma.Cd[q] : ma.y[q], base + c0, ok, VEC, yo[q][ch][0], yo[q][ch][1], ok2);
         }
     }
     const double d0 = lv ? D0[line] : 0.0;
@@ -755,7 +786,7 @@ __device__ __forceinline__ double schur_x_task(const ModeArgs &ma, const Geom &G
     return dot;
 }
 
-template <int K, int NCH, bool VEC, int NB, bool NT = false>
+template <int K, int NCH, bool VEC, int NB, bool NT = false, bool P2 = false>
 __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                                                  const double *__restrict__ D0, int nx, int ny, long nlines, int lpl_log2,
                                                  int first, int last, double *__restrict__ partials,
@@ -778,7 +809,7 @@ __global__ __launch_bounds__(256) void k_schur_x(ModeArgs ma0, ModeTab mt, Geom 
     // bit 1 of `first`: XCD-contiguous block order (consecutive workgroups go round-robin to the 8 XCDs; each then walks one eighth of the lines)
     unsigned bx = blockIdx.x;
     if ((first & 2) && gridDim.x % 8 == 0) bx = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-    const double dot = schur_x_task<K, NCH, VEC, NB, decltype(mid), false, NT>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first & 1, (long)bx * 4 + (threadIdx.x >> 6),
+    const double dot = schur_x_task<K, NCH, VEC, NB, decltype(mid), false, NT, P2>(ma, G, L, DR, D0, nx, ny, nlines, lpl_log2, first & 1, (long)bx * 4 + (threadIdx.x >> 6),
                                                                                threadIdx.x & 63, true, fuse, alpha0, beta0, fz, mid);
     if (stopped) return;                                         // decided inside, the same in every block: nothing to reduce
     if (last && partials) {

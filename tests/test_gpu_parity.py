@@ -328,6 +328,44 @@ def test_solve_adjoint(name, rt):
     s.close()
 
 
+@pytest.mark.parametrize("variant", ["default", "plain_loads_split_dot"])
+def test_iaea3d_256cube_golden(variant):
+    """The HEADLINE workload at its own size (IAEA-3D resampled to 256^3, 16.8 M cells, 2 groups: what bench.py times) against the
+    oracle's golden run (tests/golden/make_golden_256cube.py, about an hour of one core): 2 outer iterations from the flat flux with
+    the inner CG converged to 1e-10, no coarse start -- the iteration path does not hang on rounding-sensitive CG counts, so the
+    k-history is compared at 2e-9 and the flux at 1e-8, per group and overall (src/NeutFEM.cpp:1694-1802, src/solvers.cpp:577-636).
+      default                 the kernels and options the bench runs: streaming loads, the whole p.q summed in the last pass
+      plain_loads_split_dot   the same passes with plain loads and per-pass shares of p.q (z.w form in the y / z passes: what the
+                              chunked long-line passes of 512-cell meshes need)"""
+    import json
+    from bench import make_solver
+    from neutfem_amd import cases
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden_iaea3d_256cube.json")) as f:
+        r = json.load(f)["runs"]["fixed"]
+    s = make_solver(cases.iaea3d_resampled(256), 0)
+    if variant != "default":
+        s.set_option("nt_loads", 0); s.set_option("split_dot", 2)
+    s.set_tol(*r["tol"])
+    k, n = s.solve_keff()
+    h = s.history()
+    assert n == r["n_outer"] == 2 and s.info("last_path") == 0                   # host-driven classic path: k_schur_x / k_schur_s + k_cg_* (the bench's kernels)
+    np.testing.assert_allclose(h["k"], r["k_hist"], rtol=2e-9)
+    assert abs(k - r["keff"]) / r["keff"] < 2e-9
+    cg_g, cg_o = h["cg"].sum(), np.sum(r["cg"])
+    assert abs(cg_g - cg_o) <= 0.2 * cg_o, (cg_g, cg_o)                          # void cells: CG counts are rounding-sensitive on either side
+    phi = s.get_phi().ravel()
+    smp, ref = phi[::r["phi_stride"]], np.array(r["phi_samples"])
+    d = rel_l2(smp, ref)
+    per = phi.size // 2; cut = (per + r["phi_stride"] - 1) // r["phi_stride"]      # samples [0, cut) belong to group 0
+    dg = [rel_l2(smp[:cut], ref[:cut]), rel_l2(smp[cut:], ref[cut:])]
+    print(f"256^3 {variant}: k {k:.12f} vs {r['keff']:.12f}, CG {cg_g} vs {cg_o}, flux rel-L2 {d:.2e} (groups {dg[0]:.2e} / {dg[1]:.2e})")
+    assert d < 1e-8 and max(dg) < 1e-8
+    for g in range(2):                                                          # whole-vector checks, not only the samples
+        pg = phi[g * per:(g + 1) * per]
+        assert abs(pg @ pg - r["group_sq"][g]) <= 2e-8 * r["group_sq"][g] and abs(pg.sum() - r["group_sum"][g]) <= 1e-8 * abs(r["group_sum"][g])
+    s.close()
+
+
 @pytest.mark.parametrize("fuse3", [1, 0])
 def test_iaea3d_128cube_golden(fuse3):
     """The benchmark workload at 128^3 (2.1 M cells, the generator bench.py uses at 256^3) against the oracle's golden run

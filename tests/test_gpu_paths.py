@@ -12,7 +12,14 @@ pytestmark = pytest.mark.gpu
 PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
          ("resident-scans", dict(resident=1, resident_max_dofs=100000, resident_serial=0), 2),
          ("resident-one-sided", dict(resident=1, resident_max_dofs=100000, resident_two_sided=0), 2),   # one lane per line instead of a pair meeting in the middle
-         ("classic-streaming", dict(resident=0, cg_fuse3=0, nt_min_cells=0), 0)]   # the big-mesh instantiations (non-temporal loads) forced onto small meshes   # RT0-P0 small enough for LDS: "resident" is the line-per-lane variant
+         ("classic-streaming", dict(resident=0, cg_fuse3=0, nt_min_cells=0), 0),   # the big-mesh instantiations (non-temporal loads) forced onto small meshes   # RT0-P0 small enough for LDS: "resident" is the line-per-lane variant
+         # what meshes beyond 4 M cells run (no lean CG: k_finalize sums the partials), forced onto small ones: per-pass shares of p.q with the
+         # z.w form in the y / z passes (split_dot), the same with the whole dot in the last pass, the chunked long-line kernel for every y / z
+         # line, and the scalar readback through a D2H copy instead of the mapped host page
+         ("big-split-dot", dict(resident=0, cg_fuse3=0, cg_lean=0, nt_min_cells=0, split_dot=2), 0),
+         ("big-whole-dot", dict(resident=0, cg_fuse3=0, cg_lean=0, nt_min_cells=0, split_dot=0), 0),
+         ("big-chunked-lines", dict(resident=0, cg_fuse3=0, cg_lean=0, split_dot=1, s_long=1), 0),
+         ("classic-no-host-page", dict(resident=0, cg_fuse3=0, host_pub=0), 0)]
 
 
 def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
@@ -46,9 +53,28 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
         assert rel_l2(r["J"].ravel(), o.J_dofs().ravel()) < 1e-7, name
     assert res["classic-streaming"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-streaming"]["phi"], res["classic"]["phi"])   # same arithmetic, other load instructions
-    for name in ("fuse3", "resident", "resident-scans", "resident-one-sided"):
+    assert res["classic-no-host-page"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-no-host-page"]["phi"], res["classic"]["phi"])   # readback route only
+    for name in ("fuse3", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
         assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
         assert rel_l2(res[name]["phi"], res["classic"]["phi"]) < 1e-9
+
+
+@pytest.mark.parametrize("shape,rt,ng", [((24, 20, 6), 0, 2), ((40, 33, 3), 0, 2), ((9, 8, 7), 1, 2), ((47, 45, 1), 0, 2)])
+def test_paths_fixed_work_histories(shape, rt, ng):
+    """pin every path independently of knife-edge stop tests -- a FIXED number of outer iterations (no stop test can move
+    the count), inner CG converged to 1e-11, then the whole k-history at 1e-9 and the flux at 1e-8 against the oracle, per path, with
+    nf_info last_path asserted"""
+    inp = synthetic_inputs(*shape, ng=ng, seed=17)
+    tol = (0.0, 1e-11, 1e-11, 6, 3000)                            # tol_keff = 0: exactly 6 outers
+    o = make_oracle(inp, rt, rt); o.set_tol(*tol); o.SolveKeff(); ho = o.history()
+    assert ho["n_outer"] == 6
+    for name, opts, path in PATHS:
+        if name == "resident-scans" and shape[0] > 128:
+            path = 0
+        r = _run(inp, rt, rt, tol, opts)
+        assert r["path"] == path and r["n"] == 6, (name, r["path"], r["n"])
+        np.testing.assert_allclose(r["hk"], ho["k"], rtol=1e-9, err_msg=name)
+        assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
 
 
 @pytest.mark.parametrize("name,rt", [("iaea2d", 0), ("koeberg2d", 0), ("koeberg2d", 1), ("iaea2d", 1), ("biblis2d", 0), ("zion2d", 0)])
