@@ -113,6 +113,12 @@ struct nf_team {
     // CgScalars::err), keeps issuing the collectives of the schedule without the compute ("poisoned"), and returns its own error
     // once the flag has come back; the other ranks return NF_ERR_REMOTE at the same iteration.
     double *d_errsrc = nullptr;     // 1 double, 0 = fine
+    // Vector reduce (multi-rank, one slab per rank, equal slab shapes): the block partials of p.q and |r|^2 are all-reduced as they are
+    // (a few KB: still latency-bound) into d_vec and the consuming kernels sum them, every block redundantly, like the lean CG of an
+    // undivided mesh -- the two one-block k_finalize launches per CG iteration leave the critical path (7 -> 5 kernels per rank).
+    double *d_vec = nullptr; long vec_stride = 0;          // 2 rows: all-reduced p.q partials, all-reduced |r|^2 partials (+ flag slot each)
+    int vec_cnt_pq = 0, vec_cnt_rr = 0; bool vec_ok = false; int opt_vec_reduce = 1, last_vec_reduce = 0;
+    bool dry = false;               // launch functions only report their partial counts
     bool poisoned = false; int poison_rc = 0; char poison_msg[256] = { 0 };
     int xchg_in_apply = 0;          // interface exchanges issued since the current Schur apply began
     long cg_iter_total = 0;         // CG iterations launched since the team was created (NEUTFEM_INJECT_FAIL=<rank>:<iteration>)
@@ -338,7 +344,7 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
-    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_errsrc); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
+    dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_errsrc); dfree(T->d_vec); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
     if (T->h_pub) (void)hipHostFree(T->h_pub);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
     if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
@@ -571,7 +577,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank);
+    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce);
 #undef K
     return -1;
 }
@@ -833,6 +839,7 @@ static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
     return NF_OK;
 }
 
+static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &G, int last, double *partials, const CgScalars *cg, int *nparts, int zmode);
 // build-time: S_red = own half + neighbour's half for every separator; checks that separators decouple
 static int team_prepare(nf_team *T)
 {
@@ -886,6 +893,25 @@ static int team_prepare(nf_team *T)
             }
             T->sep_sweeps = m;
         }
+    }
+    // vector reduce: partial counts of the accumulation pass (z lines, mode 2) and of k_cg_rupdate, equal on every rank?
+    T->vec_ok = false;
+    if (T->rccl_reduce && T->nproc > 1 && T->slabs.size() == 1 && T->slabs[0]->nloc == 1 && (T->slabs[0]->if_lo || T->slabs[0]->if_hi)) {
+        nf_solver *S = T->slabs[0];
+        int np = 0;
+        T->dry = true;
+        const int rc = launch_s(S, 2, 0, mode_args(S, 0, 2, 0, S->d_p, S->d_q), make_geom(S), 1, T->d_partials, nullptr, &np, 2);
+        T->dry = false;
+        NFCHK(rc);
+        double v[4] = { (double)np, -(double)np, (double)grid_for(S->nphi), -(double)grid_for(S->nphi) };
+        HIPCHK(hipMemcpyAsync(T->d_red, v, sizeof v, hipMemcpyHostToDevice, T->stream));
+        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 4, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
+        HIPCHK(hipMemcpyAsync(v, T->d_red, sizeof v, hipMemcpyDeviceToHost, T->stream));
+        HIPCHK(hipStreamSynchronize(T->stream));
+        T->vec_cnt_pq = np; T->vec_cnt_rr = grid_for(S->nphi);
+        T->vec_stride = T->slab_cap + 2;
+        T->vec_ok = v[0] == -v[1] && v[2] == -v[3] && np > 0 && np < T->slab_cap && T->vec_cnt_rr < T->slab_cap;
+        if (T->vec_ok && !T->d_vec) { NFCHK(dalloc(&T->d_vec, (size_t)T->vec_stride * 2)); HIPCHK(hipMemset(T->d_vec, 0, (size_t)T->vec_stride * 2 * sizeof(double))); }
     }
     T->linked_ready = true;
     return NF_OK;
@@ -1038,6 +1064,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     // whole wavefronts: the reductions use data-parallel-primitive moves and read lane 63 (threads beyond TX * NSEG only keep the barriers company)
     dim3 grid((unsigned)((S->nx + TX - 1) / TX), (unsigned)nouter, (unsigned)mt.n), block((unsigned)((TX * NSEG + 63) / 64 * 64));
     if (nparts) *nparts = (int)(grid.x * grid.y * grid.z);
+    if (T->dry) return NF_OK;
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
     hipStream_t st = T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
@@ -1343,6 +1370,15 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     // returns when the flag has stopped every rank -- at the same iteration everywhere.
     const bool multi = T->nproc > 1;
     bool any_if = false; for (auto *S : T->slabs) any_if |= S->if_lo || S->if_hi;
+    // vector reduce (see nf_team::d_vec): row 0 of the partial buffer = this rank's p.q partials + flag slot, row 1 = |r|^2 partials + flag slot
+    const bool vred = tlean && multi && ns == 1 && T->vec_ok && T->opt_vec_reduce;
+    double *send_pq = T->d_partials, *send_rr = T->d_partials + T->partial_stride;
+    double *vec_pq = T->d_vec, *vec_rr = vred ? T->d_vec + T->vec_stride : nullptr;
+    T->last_vec_reduce = vred ? 1 : 0;
+    if (vred) {                                                   // other kernels use these rows between solves: clear the two flag slots
+        HIPCHK(hipMemsetAsync(send_pq + T->vec_cnt_pq, 0, sizeof(double), T->stream));
+        HIPCHK(hipMemsetAsync(send_rr + T->vec_cnt_rr, 0, sizeof(double), T->stream));
+    }
     auto bad = [&](int code) -> bool {                            // true: leave the loop (single process); false: carry on (poisoned or fine)
         if (code == NF_OK) return false;
         if (!multi) { rc = code; return true; }
@@ -1350,6 +1386,10 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             T->poisoned = true; T->poison_rc = code; snprintf(T->poison_msg, sizeof T->poison_msg, "%s", nf_last_error());
             const double one = 1.0;
             (void)hipMemcpyAsync(T->d_errsrc, &one, sizeof one, hipMemcpyHostToDevice, T->stream);
+            if (vred) {                                           // the flag slots of the two vectors this rank sends from now on
+                (void)hipMemcpyAsync(send_pq + T->vec_cnt_pq, &one, sizeof one, hipMemcpyHostToDevice, T->stream);
+                (void)hipMemcpyAsync(send_rr + T->vec_cnt_rr, &one, sizeof one, hipMemcpyHostToDevice, T->stream);
+            }
             (void)hipStreamSynchronize(T->stream);               // `one` lives on this stack frame; the stream may also have to recover from the failed call
             (void)hipGetLastError();
         }
@@ -1375,7 +1415,8 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 continue;
             }
             if (lean) T->slabs[0]->lean = CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 };
-            if (tlean) for (auto *S : T->slabs) S->lean_z1 = CgLean{ T->d_cg, T->d_red + 2, -1, index & 1, index == 0 ? 1 : 0 };
+            if (tlean) for (auto *S : T->slabs) S->lean_z1 = vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, index & 1, index == 0 ? 1 : 0, T->vec_cnt_rr }
+                                                                   : CgLean{ T->d_cg, T->d_red + 2, -1, index & 1, index == 0 ? 1 : 0 };
             T->xchg_in_apply = 0;
             int ra = NF_OK;
             if (multi && T->rank == T->inject_rank && global_it == T->inject_iter)
@@ -1389,6 +1430,17 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 for (int k = T->xchg_in_apply; k < 1 + T->sep_sweeps; ++k) (void)exchange_planes(T, k == 0 ? 0 : 2, 0, T->comm_stream);
                 (void)hipEventRecord(T->ev_xchg, T->comm_stream); (void)hipStreamWaitEvent(T->stream, T->ev_xchg, 0);
                 for (int i = 0; i < ns; ++i) acnt[i] = 0;
+            }
+            if (vred) {
+                // the partial vectors themselves cross the ranks; their consumers sum them (CgLean with a count and a flag slot)
+                auto allred = [&](double *send, double *recv, int cnt) -> int { NCCLCHK(g_rccl.AllReduce(send, recv, (size_t)cnt + 1, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream)); return NF_OK; };
+                if (!T->poisoned && acnt[0] != T->vec_cnt_pq) { if (bad(fail(NF_ERR_STATE, "vector reduce: the accumulation pass left %d partials, %d were agreed", acnt[0], T->vec_cnt_pq))) break; }
+                if (bad(allred(send_pq, vec_pq, T->vec_cnt_pq))) break;
+                if (!T->poisoned)
+                    hipLaunchKernelGGL(k_cg_rupdate, dim3(gcnt[0]), dim3(256), 0, T->stream, T->slabs[0]->d_r, T->slabs[0]->d_q, T->slabs[0]->nphi, T->d_cg, send_rr,
+                                       CgLean{ T->d_cg, vec_pq, T->vec_cnt_pq, index & 1, 0, T->vec_cnt_pq });
+                if (bad(allred(send_rr, vec_rr, T->vec_cnt_rr))) break;
+                continue;
             }
             if (tlean) {
                 if (bad(team_reduce(T, acnt, T->d_red))) break;   // d_red[0] = p.q, d_red[1] = error flags
@@ -1427,7 +1479,8 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             if (pub_wait(T, seq, &sc, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
         } else {
             if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
-            if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, T->d_red + 2, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
+            if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, launched & 1, 0, T->vec_cnt_rr }
+                                                                                                 : CgLean{ T->d_cg, T->d_red + 2, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
             if (readback(T, T->d_cg, &sc, nullptr, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
         }
         if (sc.done) break;
@@ -2757,6 +2810,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
+    else if (!strcmp(key, "vec_reduce")) T->opt_vec_reduce = value != 0;
     else if (!strcmp(key, "split_dot")) T->opt_split_dot = (int)std::max(0L, std::min(2L, value));   // 0 never, 1 where a chunked pass runs, 2 always (big undivided RT0-P0 meshes)
     else if (!strcmp(key, "x_two_phase")) T->opt_x_p2 = value < 0 ? -1 : (value > 0 ? 1 : 0);
     else if (!strcmp(key, "s_long")) T->opt_s_long = value < 0 ? -1 : (value > 0 ? 1 : 0);

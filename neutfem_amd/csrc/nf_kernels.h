@@ -231,13 +231,18 @@ __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgSca
 // scalars at the end of a batch, sees the outcome of the batch's last iteration.
 __device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred);
 // count < 0: partials[0] already holds the total (slab teams: k_finalize with reduce_only + the all-reduce over ranks put it there)
-struct CgLean { CgScalars *st; const double *partials; int count; int par; int first; };
+// flag_at > 0 (count >= 0): partials[flag_at] is the error slot that travelled with the partials (multi-rank teams all-reduce the
+// vector of block partials itself and let the consumers sum it: no k_finalize launch on the critical path)
+struct CgLean { CgScalars *st; const double *partials; int count; int par; int first; int flag_at; };
 __device__ __forceinline__ double lean_total(const CgLean &lean, double *sred)
 {
     return lean.count < 0 ? lean.partials[0] : strided_total(lean.partials, lean.count, sred);
 }
 // count < 0: partials[1] is the error slot that travelled with the total (sum of the ranks' flags)
-__device__ __forceinline__ int lean_err(const CgLean &lean, double total) { return reduce_err(total, lean.count < 0 ? lean.partials[1] : 0.0); }
+__device__ __forceinline__ int lean_err(const CgLean &lean, double total)
+{
+    return reduce_err(total, lean.count < 0 ? lean.partials[1] : (lean.flag_at > 0 ? lean.partials[lean.flag_at] : 0.0));
+}
 __device__ __forceinline__ double strided_total(const double *p, int cnt, double *sred)   // blocks of >= 256 threads; result in every thread
 {
     // summed by the first 256 threads only, so that blocks of any size (and k_finalize) produce the same bits: the other

@@ -7,7 +7,7 @@
 // function that talks to the other ranks through a POSIX shared-memory segment, staging -> device copy).  Sends are
 // buffered in a one-message mailbox per ordered rank pair, so the send/recv order of neutfem_hip's grouped exchange
 // cannot deadlock; all-reduces sum in rank order on every rank (bitwise identical results everywhere, like RCCL).
-// Only what neutfem_hip needs: fp64, sum, counts <= 4 for all-reduce, nranks <= 8.
+// Only what neutfem_hip needs: fp64, sum / max, counts <= 20480 for all-reduce (scalars and the vectors of block partials), nranks <= 8.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -20,11 +20,12 @@
 
 namespace {
 const int MAXR = 8;
+const int AR_MAX = 20480;                        // doubles per all-reduce
 struct Mailbox { std::atomic<long> written, consumed; };
 struct Shared {
     std::atomic<int> joined;
     std::atomic<long> ar_arrive[MAXR];
-    double ar_val[2][MAXR][4];
+    double ar_val[2][MAXR][AR_MAX];
     Mailbox box[MAXR][MAXR];                      // [src][dst]
     // message payloads follow: box_data(src, dst) = data + (src * MAXR + dst) * cap
 };
@@ -110,7 +111,7 @@ int ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank)
     close(fd);
     if (m == MAP_FAILED) { perror("fake_rccl mmap"); return 1; }
     c->sh = (Shared *)m; c->data = (double *)((char *)m + sizeof(Shared));
-    if (hipHostMalloc((void **)&c->stage_ar, 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
+    if (hipHostMalloc((void **)&c->stage_ar, AR_MAX * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
     for (int r = 0; r < nranks; ++r) {
         if (hipHostMalloc((void **)&c->stage_send[r], c->cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
         if (hipHostMalloc((void **)&c->stage_recv[r], c->cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
@@ -136,7 +137,7 @@ int ncclGroupStart() { return 0; }
 int ncclGroupEnd() { return 0; }
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t st)
 {
-    if (dtype != 8 || (op != 0 && op != 2) || count > 4) return 1;               // ncclSum / ncclMax
+    if (dtype != 8 || (op != 0 && op != 2) || count > (size_t)AR_MAX) return 1;               // ncclSum / ncclMax
     if (hipMemcpyAsync(c->stage_ar, send, count * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
     if (hipLaunchHostFunc(st, cb_allreduce, new Op{ c, -1, count, ++c->ar_seq, op }) != hipSuccess) return 1;
     return hipMemcpyAsync(recv, c->stage_ar, count * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : 1;

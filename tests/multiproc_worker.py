@@ -40,6 +40,8 @@ def main():
     dist.broadcast(idt, 0)
     t.comm_init(bytes(idt.numpy().tobytes()), world, rank)
     assert t.head.info("n_ranks") == world and t.head.info("rank") == rank
+    if os.environ.get("NEUTFEM_TEST_VEC_REDUCE") is not None:     # A/B of the vector all-reduce of block partials (nf_set_option "vec_reduce")
+        t.head.set_option("vec_reduce", int(os.environ["NEUTFEM_TEST_VEC_REDUCE"]))
     # 1. distributed Schur apply
     xg = np.random.default_rng(4).standard_normal((nz, ny, nx))
     y = t.schur_apply(1, xg[k0:k1]) if rt == 0 else np.zeros((k1 - k0, ny, nx))
@@ -55,7 +57,8 @@ def main():
     phi = t.get_phi_local() if rt == 0 else np.concatenate([s.get_phi().reshape(2, -1) for s in t.slabs], axis=1)
     J = t.get_J_local() if (not use_diag and rt == 0) else None                 # collective: the z currents cross slabs
     ys = [None] * world; ps = [None] * world; ks = [None] * world; js = [None] * world
-    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n), ks if rank == 0 else None)
+    vec = t.head.info("vec_reduce")                               # 1: the last CG solve all-reduced the partial vectors themselves (no k_finalize)
+    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n, vec), ks if rank == 0 else None)
     dist.gather_object((J, k1 - k0), js if rank == 0 else None)
     if rank == 0:
         extra = {}
@@ -67,7 +70,8 @@ def main():
                 z = Jr[:, nxf + nyf:].reshape(2, nzr + 1, ny * nx)
                 zs.append(z if r == world - 1 else z[:, :-1])
             extra["J"] = np.concatenate([np.concatenate(xs, axis=1), np.concatenate(ysf, axis=1), np.concatenate(zs, axis=1).reshape(2, -1)], axis=1)
-        np.savez(out, y=np.concatenate(ys, axis=0), phi=np.concatenate(ps, axis=1), k=np.array([v[0] for v in ks]), n=np.array([v[1] for v in ks]), x=xg, **extra)
+        np.savez(out, y=np.concatenate(ys, axis=0), phi=np.concatenate(ps, axis=1), k=np.array([v[0] for v in ks]), n=np.array([v[1] for v in ks]),
+                 vec=np.array([v[2] for v in ks]), x=xg, **extra)
     dist.barrier()
     t.close()
     dist.destroy_process_group()

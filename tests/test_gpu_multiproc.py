@@ -65,6 +65,9 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     o = make_oracle(inp)
     assert rel_l2(res["y"].ravel(), o.schur_apply(1, res["x"].ravel())) < 1e-12
     assert np.ptp(res["k"]) == 0.0 and np.ptp(res["n"]) == 0          # every rank returns the same k and outer count
+    # one slab per rank, equal slabs, full Schur path: the block partials themselves were all-reduced (5 kernels per CG iteration and
+    # rank instead of 7); several slabs per rank or the diagonal path: the k_finalize route
+    assert (res["vec"] == (1 if (per == 1 and use_diag == 0) else 0)).all(), res["vec"]
     s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)       # the same fixed work, undivided
     ks, ns = (s.solve_keff(use_diag=True, use_cmfd=use_diag == 2)) if use_diag else s.solve_keff(True, [2, 1, 2])
     assert int(res["n"][0]) == ns == 16
@@ -73,6 +76,22 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     if not use_diag:                                              # currents: z faces through the partition method across ranks
         assert rel_l2(res["J"].ravel(), s.get_J().ravel()) < 1e-6
     s.close()
+
+
+def test_vector_reduce_matches_the_scalar_route(tmp_path):
+    """the same 3-rank solve with the vector all-reduce of block partials off (k_finalize + 2-double all-reduces): same outer count,
+    k and flux to rounding (the two routes sum the same partials in a different order)"""
+    outs = []
+    for flag in ("1", "0"):
+        e = _env(); e["NEUTFEM_TEST_VEC_REDUCE"] = flag
+        out = str(tmp_path / f"res{flag}.npz")
+        bad, logs = _run_ranks(3, [out, 1, 0, 16], tmp_path, env=e)
+        assert bad is None, bad + "\n" + logs
+        outs.append(np.load(out))
+    a, b = outs
+    assert (a["vec"] == 1).all() and (b["vec"] == 0).all()
+    assert int(a["n"][0]) == int(b["n"][0]) and abs(a["k"][0] - b["k"][0]) / b["k"][0] < 1e-11
+    assert rel_l2(a["phi"].ravel(), b["phi"].ravel()) < 1e-9
 
 
 def test_two_ranks_rt1p1(tmp_path):
