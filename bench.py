@@ -292,9 +292,15 @@ def main():
         pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_[sc]<(\d+, )?1,", "schur_z": r"k_schur_[sc]<(\d+, )?2,", "schur_apply": r"k_apply3<"}[dom["name"]]
         hits = [k for k in pmc if re.match(pat, k)]
         key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None
-        if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from summarize import kernel_source_hash
+        fresh = pj.get("kernel_source_sha256") == kernel_source_hash()
+        if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc and not fresh:
+            # the newest committed profile was taken with other kernel sources: no figure rather than a stale one
+            traffic_source = dict(file="profiles/" + prof, stale=True, why="kernel sources changed since this profile was collected (sha256 of nf_kernels.h + neutfem_hip.hip differs): traffic = null")
+        elif a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:
             traffic = round(pmc[key]["hbm_bytes_per_cell"] * N)
-            traffic_source = dict(file="profiles/" + prof, kernel=key, measured_in_this_run=False,
+            traffic_source = dict(file="profiles/" + prof, kernel=key, measured_in_this_run=False, kernel_sources_match=True,
                                   how="separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE) of `python bench.py`; bytes per cell x cells of this run",
                                   tag=pj.get("tag"), commit=pj.get("commit"))
     except Exception:

@@ -894,23 +894,29 @@ static int team_prepare(nf_team *T)
             T->sep_sweeps = m;
         }
     }
-    // vector reduce: partial counts of the accumulation pass (z lines, mode 2) and of k_cg_rupdate, equal on every rank?
+    // vector reduce: partial counts of the accumulation pass (z lines, mode 2) and of k_cg_rupdate, equal on every rank?  EVERY rank of a
+    // multi-rank team takes part in this all-reduce, eligible or not (an ineligible rank contributes zeros, which makes max != -min
+    // and switches the path off everywhere): a collective behind a rank-local condition would be a hang.
     T->vec_ok = false;
-    if (T->rccl_reduce && T->nproc > 1 && T->slabs.size() == 1 && T->slabs[0]->nloc == 1 && (T->slabs[0]->if_lo || T->slabs[0]->if_hi)) {
+    if (T->rccl_reduce && T->nproc > 1) {
         nf_solver *S = T->slabs[0];
+        const bool eligible = T->slabs.size() == 1 && S->nloc == 1 && S->dim == 3 && (S->if_lo || S->if_hi);
         int np = 0;
-        T->dry = true;
-        const int rc = launch_s(S, 2, 0, mode_args(S, 0, 2, 0, S->d_p, S->d_q), make_geom(S), 1, T->d_partials, nullptr, &np, 2);
-        T->dry = false;
-        NFCHK(rc);
-        double v[4] = { (double)np, -(double)np, (double)grid_for(S->nphi), -(double)grid_for(S->nphi) };
+        if (eligible) {
+            T->dry = true;
+            const int rc = launch_s(S, 2, 0, mode_args(S, 0, 2, 0, S->d_p, S->d_q), make_geom(S), 1, T->d_partials, nullptr, &np, 2);
+            T->dry = false;
+            if (rc != NF_OK) np = 0;                              // not an error here: the scalar route serves
+        }
+        const int nr = eligible ? grid_for(S->nphi) : 0;
+        double v[4] = { (double)np, -(double)np, (double)nr, -(double)nr };
         HIPCHK(hipMemcpyAsync(T->d_red, v, sizeof v, hipMemcpyHostToDevice, T->stream));
         NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 4, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
         HIPCHK(hipMemcpyAsync(v, T->d_red, sizeof v, hipMemcpyDeviceToHost, T->stream));
         HIPCHK(hipStreamSynchronize(T->stream));
-        T->vec_cnt_pq = np; T->vec_cnt_rr = grid_for(S->nphi);
+        T->vec_cnt_pq = np; T->vec_cnt_rr = nr;
         T->vec_stride = T->slab_cap + 2;
-        T->vec_ok = v[0] == -v[1] && v[2] == -v[3] && np > 0 && np < T->slab_cap && T->vec_cnt_rr < T->slab_cap;
+        T->vec_ok = eligible && v[0] == -v[1] && v[2] == -v[3] && np > 0 && np < T->slab_cap && nr > 0 && nr < T->slab_cap;
         if (T->vec_ok && !T->d_vec) { NFCHK(dalloc(&T->d_vec, (size_t)T->vec_stride * 2)); HIPCHK(hipMemset(T->d_vec, 0, (size_t)T->vec_stride * 2 * sizeof(double))); }
     }
     T->linked_ready = true;

@@ -40,6 +40,17 @@ def counters(root, counter):
     return out
 
 
+def kernel_source_hash():
+    """sha256 over the device sources: bench.py reports a profile's traffic figure only while the kernels are the ones that were profiled"""
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for fn in ("nf_kernels.h", "neutfem_hip.hip"):
+        with open(os.path.join(here, "neutfem_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     cells = 256 ** 3
@@ -72,7 +83,8 @@ def main():
                           read_bytes_per_cell_corrected=round(2.0 * fm * 1024 / cells, 3), write_bytes_per_cell=round(wm * 1024 / cells, 3),
                           hbm_bytes_per_cell=round((2.0 * fm + wm) * 1024 / cells, 3))
     commit = os.environ.get("NEUTFEM_COMMIT")                     # the GPU box has no .git: collect.sh is given the commit by the caller
-    doc = dict(tag=tag, commit=commit,
+    src_hash = kernel_source_hash()
+    doc = dict(tag=tag, commit=commit, kernel_source_sha256=src_hash,
                command="profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, each with --kernel-trace only)",
                mesh="IAEA-3D resampled 256^3", cells=cells,
                units="counter values are KiB per dispatch (median of the upper half of the dispatches); bytes_per_cell = KiB*1024/cells",
