@@ -167,6 +167,16 @@ int nf_profile_reset(nf_handle h);
 int nf_timers(nf_handle h, char *json_buf, size_t len);
 /* times `reps` back-to-back Schur applies on group g (random x) with HIP events; average ms per apply */
 int nf_time_schur_apply(nf_handle h, int g, int reps, double *avg_ms);
+/* LocalMatrices::Compute(e, D, Sigma) (src/FEM.cpp:748-953) on the device, literally: the dense A_loc (n_Jloc x n_Jloc), B_loc
+ * (n_loc x n_Jloc) and C_loc (n_loc x n_loc) of `n_elems` elements of group g by the reference's tensor Gauss quadrature (order
+ * 2 max(k, m) + 3 with its 7 -> 5-point fallback, include/FEM.hpp:115-120), row-major like GetA / GetB / GetC, D = D_g(e),
+ * Sigma = SigR_g(e); local DOF order of src/FEM.cpp:729-745.  One element per workgroup, quadrature points and basis values
+ * staged in LDS.  The solver itself never forms these matrices (closed forms); this entry exists to check them
+ * against the quadrature on the device and to measure the one dense contraction of the code base in both forms:
+ * variant 0 = fp64 FMA, 1 = v_mfma_f64_16x16x4_f64.  reps >= 1 timed launches, average ms in *avg_ms (may be NULL).
+ * Needs nf_upload_xs (not nf_build). */
+int nf_local_matrices(nf_handle h, int g, int n_elems, const int *elems_host, double *A_host, double *B_host, double *C_host,
+                      int variant, int reps, double *avg_ms);
 /* HBM microbenchmark: `reps` device-to-device streaming copies of `bytes` (read + write counted) -> GB/s; the
  * roofline is reported against the 8 TB/s spec and against this measured figure */
 int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);

@@ -15,7 +15,7 @@ SYMBOLS = [
     "nf_comm_init", "nf_comm_selftest", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_coarsen", "nf_prolong", "nf_timers", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
-    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy", "nf_progress",
+    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy", "nf_progress", "nf_local_matrices",
     "nf_set_option", "nf_mem_info", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
 
@@ -80,6 +80,7 @@ def load():
     L.nf_time_schur_apply.argtypes = [vp, C.c_int, C.c_int, dp]
     L.nf_time_device_copy.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.nf_progress.argtypes = [vp, C.POINTER(C.c_long)]
+    L.nf_local_matrices.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp, dp, C.c_int, C.c_int, dp]
     L.nf_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.nf_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.nf_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -287,6 +288,18 @@ class HipSolver:
 
     def time_schur_apply(self, g, reps):
         ms = C.c_double(); self._chk(self.L.nf_time_schur_apply(self.h, g, reps, C.byref(ms))); return ms.value
+
+    def local_matrices(self, g, elems, variant=0, reps=1):
+        """LocalMatrices::Compute on the device for the listed elements: (A, B, C, avg_ms) with A (n, nJ, nJ), B (n, nP, nJ), C (n, nP, nP)"""
+        el = np.ascontiguousarray(elems, dtype=np.int32); n = el.size
+        k, m, dim = self.info("rt_order"), self.info("p_order"), self.dim
+        nf, ni = (k + 1) ** (dim - 1), k * (k + 1) ** (dim - 1)
+        nJ, nP = dim * (2 * nf + ni), (m + 1) ** dim
+        A, B, Cm = np.zeros((n, nJ, nJ)), np.zeros((n, nP, nJ)), np.zeros((n, nP, nP))
+        ms = C.c_double()
+        self._chk(self.L.nf_local_matrices(self.h, g, n, el.ctypes.data_as(C.POINTER(C.c_int)), A.ctypes.data_as(C.POINTER(C.c_double)),
+                                           B.ctypes.data_as(C.POINTER(C.c_double)), Cm.ctypes.data_as(C.POINTER(C.c_double)), variant, reps, C.byref(ms)))
+        return A, B, Cm, ms.value
 
     def progress(self):
         """completed outer iterations of the running / last solve_keff (callable from another thread)"""

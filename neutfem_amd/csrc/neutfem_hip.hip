@@ -12,6 +12,7 @@
 // scalars, all enqueued on the team's stream -- the host never waits for them.
 #include "../../include/neutfem_hip.h"
 #include "nf_kernels.h"
+#include "nf_assembly.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -147,6 +148,8 @@ struct nf_team {
     int opt_s_tx = 0, opt_s_seg = 0, opt_wsmin = 0;       // tuning overrides (nf_set_option)
     int opt_x_p2 = 0;                                     // x pass inside CG: two load phases (k_schur_x P2); measured no gain, off
     int opt_split_dot = 1;                                // big undivided RT0-P0 meshes: per-pass shares of p.q (team_schur_apply)
+    int opt_s_long_dirs = 3;                              // directions that may take the chunked kernel: bit 0 = y, bit 1 = z
+    int s_long_min_y = 255;                               // y lines longer than this take the chunked kernel (s_long_min: z lines)
     int opt_s_long = -1, s_long_min = 256;                // chunked long-line pass (k_schur_c): -1 auto (lines longer than s_long_min), 0 off, 1 always
     size_t lds_limit = 160 * 1024;                        // dynamic LDS a block may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock at team creation)
     // fused-direction CG (two launches per iteration) up to this many cells.  Measured crossover against the four-launch lean path after
@@ -575,7 +578,7 @@ long nf_info(nf_handle S, const char *key)
     nf_team *T = S->team;
 #define K(s, v) if (!strcmp(key, s)) return (long)(v)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
-    K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("last_outer", T->last_outer);
+    K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("rt_order", S->k); K("p_order", S->m); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
     K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce);
 #undef K
@@ -1019,10 +1022,16 @@ static ChunkPlan chunk_plan(const nf_solver *S, int d)
 {
     ChunkPlan P; const nf_team *T = S->team;
     const int n = d == 1 ? S->ny : S->nz;
-    if (S->nb != 0 || d < 1 || d >= S->dim || (d == 2 && (S->if_lo || S->if_hi))) return P;
-    if (!(T->opt_s_long == 1 || (T->opt_s_long < 0 && n > T->s_long_min)) || (size_t)S->N * sizeof(double) >= (1ull << 32)) return P;
+    if (S->nb != 0 || d < 1 || d >= S->dim || (d == 2 && (S->if_lo || S->if_hi)) || !((T->opt_s_long_dirs >> (d - 1)) & 1)) return P;
+    // y lines already from 256 cells (32 columns x 512 threads, two blocks per CU: y 128 -> 120 us inside CG at 256^3, 510 -> 502 us per
+    // iteration; nothing at 192^3, a loss at 128^3); z lines from 257: the last pass would need the split dot product, which eats its
+    // 6 us at 256^3 (profiles/r03_i_ab_cg_chunked_y.txt)
+    const int nmin = d == 1 ? T->s_long_min_y : T->s_long_min;
+    if (!(T->opt_s_long == 1 || (T->opt_s_long < 0 && n > nmin)) || (size_t)S->N * sizeof(double) >= (1ull << 32)) return P;
     P.NS = (n + 15) / 16;                                        // segments of 8 cells per chunk, two chunks
-    P.TX = T->opt_s_tx ? T->opt_s_tx : 64;
+    // 32 columns: 512-thread blocks at 256-cell lines (two per CU: one block's load phase overlaps the other's scans) beat 64 columns
+    // x 1024 threads there (y 113 vs 117 us, z 116 vs 127 at 256^3, profiles/r03_h_ab_256.txt); at 512 cells 32 columns need the full 1024
+    P.TX = T->opt_s_tx ? T->opt_s_tx : 32;
     while (P.TX > 8 && P.TX * P.NS > 1024) P.TX >>= 1;
     while (P.TX > 8 && P.TX / 2 >= S->nx) P.TX >>= 1;
     P.lds = (size_t)(3 * P.TX * P.NS + 2 * P.TX + 16 + 2 * 8 * P.NS * P.TX) * sizeof(double);
@@ -1189,7 +1198,7 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
     // elsewhere the last pass sums x_i y_i with x still in its registers, which is cheaper than three sets of partials (256^3: 504 vs
     // 531 us per CG iteration, profiles/r03_e_ab_cg.txt).
     bool split = want_dot && dim >= 2 && team_is_single(T) && T->slabs[0]->nb == 0 && !T->slabs[0]->lean.st && T->opt_split_dot;
-    if (split && T->opt_split_dot < 2) { split = false; for (int d = 1; d < dim; ++d) split |= chunk_plan(T->slabs[0], d).ok; }
+    if (split && T->opt_split_dot < 2) split = chunk_plan(T->slabs[0], dim - 1).ok;      // only the LAST pass forms the dot product
     std::vector<int> totals(ns, 0);
     for (int d = 0; d < dim; ++d) {
         const int last = d == dim - 1;
@@ -2767,6 +2776,65 @@ int nf_time_schur_apply(nf_handle S, int g, int reps, double *avg_ms)
     return NF_OK;
 }
 
+// LocalMatrices::Compute on the device, literally (nf_assembly.h): A_loc, B_loc, C_loc of `n_elems` elements of group g by tensor
+// quadrature, one element per workgroup.  variant 0 = plain fp64 FMA, 1 = v_mfma_f64_16x16x4_f64.  reps > 1 repeats the launch for timing.
+int nf_local_matrices(nf_handle S, int g, int n_elems, const int *elems_host, double *A_host, double *B_host, double *C_host, int variant, int reps, double *avg_ms)
+{
+    if (!S || g < 0 || g >= S->ng || n_elems < 1 || !elems_host || !A_host || !B_host || !C_host || variant < 0 || variant > 1 || reps < 1)
+        return fail(NF_ERR_ARG, "nf_local_matrices: bad arguments");
+    if (!S->xs_uploaded) return fail(NF_ERR_STATE, "nf_local_matrices: call nf_upload_xs first");
+    for (int i = 0; i < n_elems; ++i) if (elems_host[i] < 0 || elems_host[i] >= S->N) return fail(NF_ERR_ARG, "nf_local_matrices: element %d out of range", elems_host[i]);
+    HIPCHK(hipSetDevice(S->device));
+    nf_team *T = S->team; hipStream_t st = T->stream;
+    AsmArgs P; memset(&P, 0, sizeof P);
+    P.dim = S->dim; P.k = S->k; P.m = S->m;
+    // Gauss rule of order 2 max(k, m) + 3 (src/NeutFEM.cpp:276): 3 points for RT0, 5 for RT1, and 7 -> the 5-point fallback for RT2
+    // (include/FEM.hpp:115-120)
+    if (2 * std::max(S->k, S->m) + 3 == 3) {
+        P.nq = 3; const double a = std::sqrt(0.6);
+        P.qp[0] = -a; P.qp[1] = 0.0; P.qp[2] = a; P.qw[0] = 5.0 / 9.0; P.qw[1] = 8.0 / 9.0; P.qw[2] = 5.0 / 9.0;
+    } else {
+        P.nq = 5;
+        const double p5[5] = { -0.906179845938664, -0.538469310105683, 0.0, 0.538469310105683, 0.906179845938664 };
+        const double w5[5] = { 0.236926885056189, 0.478628670499366, 0.568888888888889, 0.478628670499366, 0.236926885056189 };
+        for (int i = 0; i < 5; ++i) { P.qp[i] = p5[i]; P.qw[i] = w5[i]; }
+    }
+    int nf = 1, ni = S->k; for (int t = 1; t < S->dim; ++t) { nf *= S->k + 1; ni *= S->k + 1; }
+    const int nJ = S->dim * (2 * nf + ni); int nP = 1; for (int t = 0; t < S->dim; ++t) nP *= S->m + 1;
+    P.nx = S->nx; P.ny = S->ny; P.nz = S->nz; P.hx = S->d_hx; P.hy = S->d_hy; P.hz = S->d_hz;
+    P.D = S->d_D + (size_t)g * S->N; P.Sig = S->d_SigR + (size_t)g * S->N; P.n_elems = n_elems;
+    DevTmp<double> dA, dB, dC; int *d_el = nullptr;
+    HIPCHK(hipMalloc((void **)&dA.p, (size_t)n_elems * nJ * nJ * sizeof(double))); HIPCHK(hipMalloc((void **)&dB.p, (size_t)n_elems * nP * nJ * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&dC.p, (size_t)n_elems * nP * nP * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&d_el, (size_t)n_elems * sizeof(int)));
+    int rc = NF_OK;
+    if (hipMemcpy(d_el, elems_host, (size_t)n_elems * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = fail(NF_ERR_HIP, "nf_local_matrices: upload failed");
+    P.elems = d_el; P.A = dA.p; P.B = dB.p; P.C = dC.p;
+    const size_t lds = (size_t)(18 + 6 + 6 + 12 + 12 + 128 + 2 * 128 * 48 + 128 * 32) * sizeof(double);
+    const void *fn = variant ? (const void *)k_local_matrices<true> : (const void *)k_local_matrices<false>;
+    if (rc == NF_OK && !lds_opt_in(fn, lds)) rc = fail(NF_ERR_UNSUPPORTED, "nf_local_matrices needs %zu bytes of LDS per workgroup", lds);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (rc == NF_OK) {
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        for (int r = 0; r <= reps; ++r) {                         // one warm-up launch, then `reps` timed ones
+            if (r == 1) (void)hipEventRecord(a, st);
+            if (variant) hipLaunchKernelGGL(k_local_matrices<true>, dim3((unsigned)n_elems), dim3(256), lds, st, P);
+            else hipLaunchKernelGGL(k_local_matrices<false>, dim3((unsigned)n_elems), dim3(256), lds, st, P);
+        }
+        (void)hipEventRecord(b, st);
+        if (hipEventSynchronize(b) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(NF_ERR_HIP, "nf_local_matrices: kernel failed");
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b);
+        if (avg_ms) *avg_ms = ms / reps;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+    if (rc == NF_OK && (hipMemcpy(A_host, dA.p, (size_t)n_elems * nJ * nJ * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(B_host, dB.p, (size_t)n_elems * nP * nJ * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(C_host, dC.p, (size_t)n_elems * nP * nP * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(NF_ERR_HIP, "nf_local_matrices: download failed");
+    (void)hipFree(d_el);
+    return rc;
+}
+
 int nf_time_device_copy(nf_handle S, size_t bytes, int reps, double *gbps)
 {
     if (!S || bytes < 16 || reps < 1 || !gbps) return fail(NF_ERR_ARG, "nf_time_device_copy: bad arguments");
@@ -2820,6 +2888,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "split_dot")) T->opt_split_dot = (int)std::max(0L, std::min(2L, value));   // 0 never, 1 where a chunked pass runs, 2 always (big undivided RT0-P0 meshes)
     else if (!strcmp(key, "x_two_phase")) T->opt_x_p2 = value < 0 ? -1 : (value > 0 ? 1 : 0);
     else if (!strcmp(key, "s_long")) T->opt_s_long = value < 0 ? -1 : (value > 0 ? 1 : 0);
+    else if (!strcmp(key, "s_long_dirs")) T->opt_s_long_dirs = (int)(value & 3);
+    else if (!strcmp(key, "s_long_min_y")) T->s_long_min_y = (int)std::max(1L, std::min(1000000L, value));
     else if (!strcmp(key, "s_long_min")) T->s_long_min = (int)std::max(1L, std::min(1000000L, value));
     else if (!strcmp(key, "cg_batch")) T->cg_batch = (int)value;
     else if (!strcmp(key, "cg_fuse")) T->opt_fuse = value != 0;

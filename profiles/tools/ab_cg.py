@@ -20,7 +20,7 @@ s.upload_xs(c["D"], c["SigR"], c["NSF"], c["Chi"], c["SigS"]); s.build()
 tol = (0.0, 0.0, 1e-4, 1, 50) if kind == "checker" else (0.0, 1e-4, 1e-4, 1, 1000)
 s.set_tol(*tol); s.solve_keff()                                    # warm-up
 keys = sorted({kv.split("=")[0] for v in variants if v != "default" for kv in v.split(",")})
-defaults = dict(x_two_phase=-1, split_dot=1, s_long=-1, nt_loads=1, xcd=-1, s_tx=0, cg_lean=1)
+defaults = dict(x_two_phase=0, split_dot=1, s_long=-1, s_long_dirs=3, s_long_min=256, nt_loads=1, xcd=-1, s_tx=0, cg_lean=1, vec_reduce=1)
 for rep in range(2):
     for v in variants:
         for k in keys:
