@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 # (nx, ny, nz): y or z lines of 505 ... 2100 cells on thin meshes -- 512 / 600 / 1023 / 1024 (one segment class), 576 and 1024
 # (the lengths the round-2 wavefront scan hung on: 72 ... 128 segments), 1100 / 2047 (16-cell segments), 2100 (32-cell segments)
 LONG = [(16, 16, 512), (24, 600, 3), (8, 8, 1024), (8, 576, 2), (40, 1023, 2), (3, 5, 1023), (8, 4, 1100), (6, 3, 2047), (4, 2100, 2),
-        (70, 512, 3), (33, 3, 640), (64, 2, 515)]
+        (70, 512, 3), (33, 3, 640), (64, 2, 515),
+        # 256-cell lines: y takes the chunked kernel (32 columns x 512 threads), z the one-chunk kernel; 255 / 257 either side of both thresholds
+        (40, 256, 3), (8, 4, 256), (33, 255, 2), (9, 257, 2), (5, 3, 257), (70, 300, 2)]
 
 
 def _apply(inp, rt=0, p=0, tol=1e-12, opts=None, groups=None):
