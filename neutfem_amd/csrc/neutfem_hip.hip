@@ -334,7 +334,13 @@ static int team_alloc(nf_team *T)
     if (!T->d_out) NFCHK(dalloc(&T->d_out, 8));
     if (!T->d_red) NFCHK(dalloc(&T->d_red, 8));
     if (!T->d_errsrc) { NFCHK(dalloc(&T->d_errsrc, 1)); HIPCHK(hipMemset(T->d_errsrc, 0, sizeof(double))); }
-    if (const char *e = getenv("NEUTFEM_INJECT_FAIL")) { int r = -1; long it = -1; if (sscanf(e, "%d:%ld", &r, &it) == 2) { T->inject_rank = r; T->inject_iter = it; } }
+    // NEUTFEM_INJECT_FAIL=<rank>:<iteration>[:<min local DOFs per cell>] (tests): the optional third field keeps the injection away from
+    // the RT0-P0 coarse twin of a higher-order team, so that the non-lean reduction route of RT1 / RT2 teams is the one that is hit
+    if (const char *e = getenv("NEUTFEM_INJECT_FAIL")) {
+        int r = -1, ml = 0; long it = -1;
+        const int nf = sscanf(e, "%d:%ld:%d", &r, &it, &ml);
+        if (nf >= 2 && (nf < 3 || T->slabs.empty() || T->slabs[0]->nloc >= ml)) { T->inject_rank = r; T->inject_iter = it; }
+    }
     if (const char *e = getenv("NEUTFEM_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0) T->comm_timeout_s = v; }
     T->last_its.assign(64, 0);
     return NF_OK;

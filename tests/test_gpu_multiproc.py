@@ -124,16 +124,20 @@ def test_indivisible_coarse_factors_are_refused_by_every_rank(tmp_path):
     assert logs.count("do not divide") >= 3, logs
 
 
-def test_failing_rank_stops_every_rank_instead_of_hanging_them(tmp_path):
+@pytest.mark.parametrize("route,inject,extra,env_extra", [
+    ("vector reduce (RT0-P0, one slab per rank)", "1:40", [], {}),
+    ("scalar reduce (k_finalize + 2-double all-reduce)", "1:40", [], {"NEUTFEM_TEST_VEC_REDUCE": "0"}),
+    ("RT1-P1 team (k_finalize + k_cg_logic, no lean CG)", "1:25:4", [0, 1], {})])
+def test_failing_rank_stops_every_rank_instead_of_hanging_them(tmp_path, route, inject, extra, env_extra):
     """a rank-local error inside a solve used to return on that rank only -- the others then waited in
     ncclAllReduce until somebody killed the job.  NEUTFEM_INJECT_FAIL=1:40 makes rank 1 of 3 fail (as a refused launch would) at its
     41st CG iteration.  Expected: rank 1 raises its error flag in the all-reduces that exist anyway, keeps the collective schedule
     going, and ALL THREE ranks leave the solve at the same iteration -- rank 1 with its own error, ranks 0 and 2 with NF_ERR_REMOTE --
     within seconds, by themselves."""
     import time
-    e = _env(); e["NEUTFEM_INJECT_FAIL"] = "1:40"; e["NEUTFEM_COMM_TIMEOUT_S"] = "60"
+    e = _env(); e["NEUTFEM_INJECT_FAIL"] = inject; e["NEUTFEM_COMM_TIMEOUT_S"] = "60"; e.update(env_extra)
     t0 = time.time()
-    bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, 0, 16], tmp_path, timeout=150, env=e, wait_all=True)
+    bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, 0, 16] + extra, tmp_path, timeout=150, env=e, wait_all=True)
     assert bad == "a rank failed", (bad, logs)                     # i.e. not "timed out": every rank ended by itself
     assert time.time() - t0 < 120, logs
     per = logs.split("--- rank ")[1:]
