@@ -297,7 +297,7 @@ def main():
         fresh = pj.get("kernel_source_sha256") == kernel_source_hash()
         if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc and not fresh:
             # the newest committed profile was taken with other kernel sources: no figure rather than a stale one
-            traffic_source = dict(file="profiles/" + prof, stale=True, why="kernel sources changed since this profile was collected (sha256 of nf_kernels.h + neutfem_hip.hip differs): traffic = null")
+            traffic_source = dict(file="profiles/" + prof, stale=True, why="the device kernels changed since this profile was collected (sha256 of nf_kernels.h differs): traffic = null")
         elif a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:
             traffic = round(pmc[key]["hbm_bytes_per_cell"] * N)
             traffic_source = dict(file="profiles/" + prof, kernel=key, measured_in_this_run=False, kernel_sources_match=True,

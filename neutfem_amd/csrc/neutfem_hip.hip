@@ -2884,9 +2884,11 @@ int nf_set_option(nf_handle S, const char *key, long value)
     if (!strcmp(key, "s_tx")) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(NF_ERR_ARG, "nf_set_option: s_tx must be 0 (auto), 8, 16, 32 or 64");
         T->opt_s_tx = (int)value;
+        if (T->nproc > 1) T->linked_ready = false;               // the partial counts agreed for the vector reduce depend on the tile shape: agree again
     } else if (!strcmp(key, "s_seg")) {
         if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32) return fail(NF_ERR_ARG, "nf_set_option: s_seg must be 0 (auto), 4, 8, 16 or 32");
         T->opt_s_seg = (int)value;
+        if (T->nproc > 1) T->linked_ready = false;
     }
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));

@@ -51,6 +51,30 @@ def test_long_line_variants_agree(shape, opts):
     assert rel_l2(ya, yb) < 1e-13
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_chunked_kernel_random_shapes(seed):
+    """the chunked long-line kernel forced onto every y / z line (s_long = 1), shapes drawn at random: line lengths from 2 cells (one
+    segment, an empty second chunk) to 700, odd lengths, meshes narrower than a tile, every tile width -- against the oracle, and inside
+    a CG solve (split dot product: per-pass shares of p.q, z.w form) against the one-chunk kernels"""
+    rng = np.random.default_rng(100 + seed)
+    nx = int(rng.integers(2, 70)); ny = int(rng.integers(2, 12 if seed % 2 else 700)); nz = int(rng.integers(2, 700 if seed % 2 else 12))
+    if seed == 0: nx, ny, nz = 3, 2, 2
+    if seed == 1: nx, ny, nz = 64, 17, 33
+    inp = synthetic_inputs(nx, ny, nz, 1, seed=seed)
+    opts = dict(s_long=1, s_tx=[0, 8, 16, 32, 64][seed % 5])
+    _apply(inp, opts=opts)
+    o, s = make_oracle(inp), make_hip(inp)
+    for k, v in dict(opts, resident=0, cg_fuse3=0, cg_lean=0, split_dot=2).items():
+        s.set_option(k, v)
+    rhs = np.abs(rng.standard_normal(o.n_phi))
+    o.set_tol(1e-5, 1e-11, 1e-11, 200, 5000)
+    xo, _, its_o = o.solve_group(0, rhs)
+    xs, its_s, res = s.solve_group(0, rhs, 1e-11, 5000)
+    assert res < 1e-11 and abs(its_s - its_o) <= max(2, 0.05 * its_o), (its_s, its_o)
+    assert rel_l2(xs, xo) < 1e-9
+    s.close()
+
+
 @pytest.mark.parametrize("rt,p", [(1, 1), (2, 2), (1, 0)])
 @pytest.mark.parametrize("shape", [(6, 300, 2), (5, 3, 600), (8, 512, 1), (4, 2, 1000)])
 def test_schur_apply_long_lines_higher_order(rt, p, shape):

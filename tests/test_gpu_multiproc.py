@@ -50,6 +50,13 @@ def _run_ranks(world, args, tmp_path, timeout=200, env=None, wait_all=False):
     out = []
     for r, f in enumerate(logs):
         f.seek(0); out.append(f"--- rank {r} (rc={procs[r].returncode}) ---\n" + f.read()[-3000:]); f.close()
+    if bad is not None:                                             # pytest truncates long assertion messages: keep the ranks' output where gpurun collects it
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "multiproc_last_failure.log"), "w") as f:
+                f.write(f"{bad}\nargs: {args}\n" + "\n".join(out))
+        except OSError:
+            pass
     return bad, "\n".join(out)
 
 
