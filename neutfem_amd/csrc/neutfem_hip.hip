@@ -74,6 +74,9 @@ struct Rccl {
     int (*CommAbort)(ncclComm_t) = nullptr;          // optional: used when a peer stops answering (comm_timeout_s)
 };
 static Rccl g_rccl;
+// NEUTFEM_TRACE_COMM=1: one line on stderr per collective this rank issues (debugging the order of collectives across ranks)
+static bool trace_comm() { static int on = -1; if (on < 0) { const char *e = getenv("NEUTFEM_TRACE_COMM"); on = e && atoi(e) ? 1 : 0; } return on == 1; }
+#define TRACE_COMM(...) do { if (trace_comm()) { fprintf(stderr, "[comm] " __VA_ARGS__); fputc('\n', stderr); } } while (0)
 static const int NCCL_DOUBLE = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclFloat64 / ncclSum / ncclMax in rccl.h
 #define NCCLCHK(x) do { int r_ = (x); if (r_ != 0) return fail(NF_ERR_HIP, "%s failed: %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); } while (0)
 
@@ -831,6 +834,7 @@ static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
     nf_solver *bot = T->slabs.front(), *top = T->slabs.back();
     if (T->nproc > 1 && (bot->if_lo || top->if_hi)) {
         const size_t cnt = (size_t)bot->nlines[2] * (which == 1 ? 1 : n_modes(bot));
+        TRACE_COMM("rank %d exchange which=%d count=%zu lo=%d hi=%d poisoned=%d", T->rank, which, cnt, bot->if_lo, top->if_hi, (int)T->poisoned);
         NCCLCHK(g_rccl.GroupStart());
         if (bot->if_lo) {
             NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
@@ -941,6 +945,7 @@ static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int
     } else {
         // the sums of this rank followed by its error flag: one all-reduce of nq + 1 doubles (CgScalars::err)
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 1, T->d_red, (const double *)T->d_errsrc);
+        TRACE_COMM("rank %d allreduce finalize op=%d count=%d poisoned=%d", T->rank, op, nq + 1, (int)T->poisoned);
         NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq + 1, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
         hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, T->stream, op, T->d_red, nq, T->d_cg, out, tol, maxit, 1);
     }
@@ -954,7 +959,7 @@ static int team_reduce(nf_team *T, const std::vector<int> &counts, double *red)
     PartSegs ps = segs_for(T, counts);
     // red[0] = the sum, red[1] = this rank's error flag: both travel in the one all-reduce (the consumers read red[1], CgLean count < 0)
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, 1, T->d_cg, red, 0.0, 0, 1, red, (const double *)T->d_errsrc);
-    if (T->rccl_reduce) NCCLCHK(g_rccl.AllReduce(red, red, 2, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
+    if (T->rccl_reduce) { TRACE_COMM("rank %d allreduce reduce count=2 poisoned=%d", T->rank, (int)T->poisoned); NCCLCHK(g_rccl.AllReduce(red, red, 2, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream)); }
     return NF_OK;
 }
 
@@ -1441,13 +1446,18 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             T->xchg_in_apply = 0;
             int ra = NF_OK;
             if (multi && T->rank == T->inject_rank && global_it == T->inject_iter)
-                ra = fail(NF_ERR_HIP, "injected failure on rank %d at CG iteration %ld (NEUTFEM_INJECT_FAIL)", T->rank, global_it);
+                { ra = fail(NF_ERR_HIP, "injected failure on rank %d at CG iteration %ld (NEUTFEM_INJECT_FAIL)", T->rank, global_it); TRACE_COMM("rank %d INJECT at %ld", T->rank, global_it); }
             else if (!T->poisoned) ra = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
             if (lean) T->slabs[0]->lean = no_lean;
             if (tlean) for (auto *S : T->slabs) S->lean_z1 = no_lean;
             if (bad(ra)) break;
             if (T->poisoned && any_if) {
                 // the interface exchanges this apply still owes its neighbours: one per apply + one per separator sweep (team_endpoint_phase)
+                // with the stream dependencies of team_endpoint_phase: the exchange waits for the solver's stream (ev_z1), the reductions
+                // wait for the exchange (ev_xchg).  Without the first one the comm stream runs iterations ahead, and a transport whose
+                // operations of one process share a progress thread (the stand-in does; RCCL's proxy has the same shape) deadlocks: this
+                // rank blocks in the NEXT iteration's receive while its peers still wait for it in THIS iteration's all-reduce.
+                if (T->xchg_in_apply == 0) { (void)hipEventRecord(T->ev_z1, T->stream); (void)hipStreamWaitEvent(T->comm_stream, T->ev_z1, 0); }
                 for (int k = T->xchg_in_apply; k < 1 + T->sep_sweeps; ++k) (void)exchange_planes(T, k == 0 ? 0 : 2, 0, T->comm_stream);
                 (void)hipEventRecord(T->ev_xchg, T->comm_stream); (void)hipStreamWaitEvent(T->stream, T->ev_xchg, 0);
                 for (int i = 0; i < ns; ++i) acnt[i] = 0;
@@ -1497,12 +1507,12 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         if (lean && pub_ready(T)) {                               // the kernel that evaluates the stop tests hands the scalars to the host itself
             const unsigned long long seq = ++T->pub_seq;
             hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, T->d_pub, seq);
-            if (pub_wait(T, seq, &sc, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
+            { const int rw = pub_wait(T, seq, &sc, nullptr, 0); if (rw != NF_OK) { rc = rw; break; } }
         } else {
             if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
             if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, launched & 1, 0, T->vec_cnt_rr }
                                                                                                  : CgLean{ T->d_cg, T->d_red + 2, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
-            if (readback(T, T->d_cg, &sc, nullptr, nullptr, 0) != NF_OK) { rc = NF_ERR_HIP; break; }
+            { const int rw = readback(T, T->d_cg, &sc, nullptr, nullptr, 0); if (rw != NF_OK) { rc = rw; break; } }
         }
         if (sc.done) break;
         // after the first (predicted) batch grow geometrically: an iteration launched past convergence is five early-exit

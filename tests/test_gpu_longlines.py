@@ -57,8 +57,10 @@ def test_chunked_kernel_random_shapes(seed):
     segment, an empty second chunk) to 700, odd lengths, meshes narrower than a tile, every tile width -- against the oracle, and inside
     a CG solve (split dot product: per-pass shares of p.q, z.w form) against the one-chunk kernels"""
     rng = np.random.default_rng(100 + seed)
-    nx = int(rng.integers(2, 70)); ny = int(rng.integers(2, 12 if seed % 2 else 700)); nz = int(rng.integers(2, 700 if seed % 2 else 12))
-    if seed == 0: nx, ny, nz = 3, 2, 2
+    nx = int(rng.integers(6, 70)); ny = int(rng.integers(3, 12 if seed % 2 else 700)); nz = int(rng.integers(3, 700 if seed % 2 else 12))
+    while nx * ny * nz < 200: nx += 5
+    if seed == 0: nx, ny, nz = 30, 2, 4                            # two-cell y lines: one segment, an empty second chunk (>= 200 unknowns: below,
+                                                                   # the reference's Schur solver forms S explicitly, src/solvers.cpp:114-124)
     if seed == 1: nx, ny, nz = 64, 17, 33
     inp = synthetic_inputs(nx, ny, nz, 1, seed=seed)
     opts = dict(s_long=1, s_tx=[0, 8, 16, 32, 64][seed % 5])
