@@ -569,11 +569,17 @@ int nf_comm_selftest(nf_handle S)
         if (g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream) != 0) rc = fail(NF_ERR_HIP, "nf_comm_selftest: ncclAllReduce(max) failed");
         (void)hipMemcpyAsync(&w, T->d_red, sizeof w, hipMemcpyDeviceToHost, T->stream);
     }
+    // the vector reduce's call form: out-of-place sum of 1024 partials + 1 flag slot (b <- sum over ranks of a[0 .. 1025))
+    const size_t nv = 1025;
+    if (rc == NF_OK && g_rccl.AllReduce(a, b + n - nv, nv, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream) != 0) rc = fail(NF_ERR_HIP, "nf_comm_selftest: ncclAllReduce(sum, 1025 doubles) failed");
     std::vector<double> ha(n), hb(n);
     if (hipStreamSynchronize(T->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "nf_comm_selftest: stream failed");
     if (rc == NF_OK) {
         (void)hipMemcpy(ha.data(), a, n * sizeof(double), hipMemcpyDeviceToHost); (void)hipMemcpy(hb.data(), b, n * sizeof(double), hipMemcpyDeviceToHost);
-        if (memcmp(ha.data(), hb.data(), n * sizeof(double)) != 0) rc = fail(NF_ERR_NUMERIC, "nf_comm_selftest: received plane differs from the sent one");
+        bool vec_ok = true;                                        // every rank sends the same pattern: the sum is nproc times it
+        for (size_t i = 0; i < nv && vec_ok; ++i) vec_ok = hb[n - nv + i] == (double)T->nproc * ha[i];
+        if (memcmp(ha.data(), hb.data(), (n - nv) * sizeof(double)) != 0) rc = fail(NF_ERR_NUMERIC, "nf_comm_selftest: received plane differs from the sent one");
+        else if (!vec_ok) rc = fail(NF_ERR_NUMERIC, "nf_comm_selftest: all-reduce(sum) of a 1025-double vector returned wrong values");
         else if (T->nproc == 1 && w != 3.25) rc = fail(NF_ERR_NUMERIC, "nf_comm_selftest: all-reduce(max) returned %g", w);
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
