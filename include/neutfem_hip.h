@@ -198,7 +198,7 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   (direction, transverse mode, line) with serial sweeps instead of the segmented scans (nf_info "last_resident_serial"), up to
  *   "resident_serial_max_dofs" flux DOFs per group (default 5120, the structural limit; "resident_max_dofs" lowers it too);
  *   "resident_two_sided" (default 1): lines of at least 4 cells are swept by two lanes that meet in the middle;
- *   "direct_max_dofs" (default 2048, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
+ *   "direct_max_dofs" (default 6000, at most 8192): explicit-S branch with a dense S^-1 up to this many flux DOFs per group, beyond it
  *   CG to 1e-14 stands in (nf_info "direct_standin_unconverged" counts group solves that did not get there);
  *   "host_pub" (default 1): the host reads the CG scalars and the outer iteration's sums from a mapped host page that a one-thread
  *   kernel fills (polled), not through a device-to-host copy and a stream drain;

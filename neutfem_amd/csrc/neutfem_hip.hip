@@ -161,7 +161,7 @@ struct nf_team {
     int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, opt_resident_two_sided = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
-    long direct_max_dofs = 2048;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group
+    long direct_max_dofs = 6000;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group (the oracle's own limit: exact on both sides over the same range; 288 MB per group at 6000)
     int last_direct = 0;                                  // the last solve used: 0 CG as configured, 1 dense S^-1, 2 CG to 1e-14 standing in
     long standin_unconverged = 0;                         // group solves of the stand-in that ended above 1e-14
     // coarse twin of the team (SolveCoarse): built on the first coarse-mesh start and kept until the cross sections, the boundary

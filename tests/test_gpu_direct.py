@@ -49,6 +49,21 @@ def test_explicit_schur_branch_matches_the_exact_oracle(shape, rt, p, solver):
     s.close()
 
 
+def test_explicit_schur_beyond_2048_unknowns():
+    """round 3: the dense S^-1 of the direct branch now goes up to the oracle's own limit (6000 unknowns per group; was 2048, beyond
+    which CG to 1e-14 stood in).  55 x 55 RT0-P0 = 3025 unknowns per group, DIRECT_LDLT: the same exact solve on both sides."""
+    inp = synthetic_inputs(55, 55, 1, ng=2, seed=12)
+    o, s = _pair(inp, 0, 0, 1)
+    assert o.n_phi == 3025
+    tol = (1e-10, 1e-10, 1e-10, 40, 2000); o.set_tol(*tol); s.set_tol(*tol)
+    ko = o.SolveKeff(); ks, n = s.solve_keff()
+    assert s.info("last_direct") == 1 and n == o.info("last_outer")
+    assert abs(ks - ko) / ko < 1e-10
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-9
+    assert (s.history()["cg"] == 1).all()
+    s.close()
+
+
 def test_direct_branch_follows_rebuilds_and_size_limit():
     inp = synthetic_inputs(16, 14, 1, ng=2, seed=4)
     o, s = _pair(inp, 0, 0, 0)                                       # DIRECT_LU, 224 unknowns per group
