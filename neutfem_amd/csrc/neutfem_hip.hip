@@ -421,6 +421,18 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     const char *cb = getenv("NEUTFEM_CG_BATCH"); T->cg_batch = cb ? atoi(cb) : 0;
     *out = S;
     int rc = NF_OK;
+    // NEUTFEM_OPTS="key=value,key=value": nf_set_option on every handle at creation (A/B runs of programs that do not expose the options,
+    // e.g. bench.py with slab teams); unknown keys are reported once on stderr
+    if (const char *e = getenv("NEUTFEM_OPTS")) {
+        std::string all(e); size_t pos = 0;
+        while (pos < all.size()) {
+            const size_t c = all.find(',', pos); const std::string kv = all.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && nf_set_option(S, kv.substr(0, eq).c_str(), atol(kv.c_str() + eq + 1)) != NF_OK) fprintf(stderr, "NEUTFEM_OPTS: %s\n", nf_last_error());
+            if (c == std::string::npos) break;
+            pos = c + 1;
+        }
+    }
     auto up = [&](double **d, const std::vector<double> &h) {
         if (rc != NF_OK) return;
         rc = dalloc(d, h.size());
@@ -1053,6 +1065,13 @@ static ChunkPlan chunk_plan(const nf_solver *S, int d)
     while (P.TX > 8 && P.TX / 2 >= S->nx) P.TX >>= 1;
     P.lds = (size_t)(3 * P.TX * P.NS + 2 * P.TX + 16 + 2 * 8 * P.NS * P.TX) * sizeof(double);
     P.ok = P.TX * P.NS <= 1024 && P.lds <= T->lds_limit;
+    // up to 256 cells per line the one-chunk kernel has 32 columns too, and the chunked one only wins through two blocks per CU
+    // overlapping: that needs tiles to overlap with.  A 256 x 256 x 32 slab has 256 of them -- one per CU -- and loses (y 22.8 vs 20.8 us,
+    // 8-slab loopback 983 vs 971 us per CG iteration, profiles/r03_n_thin_slab_tiles.txt); 256^3 has 2048 and wins.
+    if (P.ok && n <= 256 && T->opt_s_long < 1) {
+        const long tiles = (long)((S->nx + P.TX - 1) / P.TX) * (d == 1 ? S->nz : S->ny);
+        if (tiles < 1024) P.ok = false;
+    }
     return P;
 }
 
