@@ -104,6 +104,10 @@ struct nf_team {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;   // interface planes travel here while the x / y passes run on `stream`
+    // small slabs (a rank's share at strong-scaling sizes): a pass on 2 M cells does not fill the chip, so the y pass runs BESIDE the x
+    // pass on a stream of its own, into its own vector; the accumulation pass of the z lines adds the two (SlabArgs::yadd)
+    hipStream_t y_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int opt_xy_overlap = 1; long xy_overlap_max_cells = 6L << 20;
     hipEvent_t ev_z1 = nullptr, ev_xchg = nullptr;
     int nproc = 1, rank = 0;
     ncclComm_t comm = nullptr;
@@ -210,6 +214,8 @@ struct nf_solver {
     CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
     CgLean lean_z1 = { nullptr, nullptr, 0, 0, 0 };     // slab teams: the endpoint pass of the z lines consumes the all-reduced |r|^2
     bool zw_dot = false;                                // this apply: the y / z passes emit T_a sum z_f w_f as their share of x.y (team_schur_apply, split)
+    hipStream_t pass_stream = nullptr;                  // this launch goes to another stream than the team's (x || y on small slabs)
+    bool pass_noacc = false; const double *pass_yadd = nullptr;   // SlabArgs::noacc / yadd of this launch
     double *d_Jz = nullptr; bool jz_valid = false;      // slabs: z currents of the last solve, ng * nJz face DOFs (nf_get_J)
     double *d_Jzb = nullptr;                            // slabs, RT1+: z bubbles of the local cells, ng * N * ni
     // CMFD (include/NeutFEM.hpp:119-143): D~ / D^ per direction (ng * faces), PCG work vectors, scalars
@@ -359,6 +365,9 @@ static void team_free(nf_team *T)
     dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_errsrc); dfree(T->d_vec); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
     if (T->h_pub) (void)hipHostFree(T->h_pub);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
+    if (T->y_stream) { (void)hipStreamSynchronize(T->y_stream); (void)hipStreamDestroy(T->y_stream); }
+    if (T->ev_fork) (void)hipEventDestroy(T->ev_fork);
+    if (T->ev_join) (void)hipEventDestroy(T->ev_join);
     if (T->ev_z1) (void)hipEventDestroy(T->ev_z1);
     if (T->ev_xchg) (void)hipEventDestroy(T->ev_xchg);
     if (T->stream) (void)hipStreamDestroy(T->stream);
@@ -442,7 +451,9 @@ static int create_impl(int rt_order, int p_order, int ng, int nxb, const double 
     if (hipStreamCreateWithFlags(&T->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(NF_ERR_HIP, "hipStreamCreate failed");
     if (rc == NF_OK && (if_lo || if_hi)) {
         if (hipStreamCreateWithFlags(&T->comm_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T->ev_z1, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&T->ev_xchg, hipEventDisableTiming) != hipSuccess) rc = fail(NF_ERR_HIP, "comm stream / event creation failed");
+            hipEventCreateWithFlags(&T->ev_xchg, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&T->y_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&T->ev_join, hipEventDisableTiming) != hipSuccess) rc = fail(NF_ERR_HIP, "comm stream / event creation failed");
     }
     up(&S->d_hx, S->hx); up(&S->d_hy, S->hy); up(&S->d_hz, S->hz); up(&S->d_xb, S->xb); up(&S->d_yb, S->yb); up(&S->d_zb, S->zb);
     const size_t NN = (size_t)S->nphi * ng;
@@ -1117,8 +1128,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     if (nparts) *nparts = (int)(grid.x * grid.y * grid.z);
     if (T->dry) return NF_OK;
     const double *L = S->d_L[d] + g * N, *DR = S->d_DR[d] + g * N, *D0 = S->d_D0[d] + g * S->nlines[d];
-    hipStream_t st = T->stream;
+    hipStream_t st = S->pass_stream ? S->pass_stream : T->stream;
     SlabArgs sa; memset(&sa, 0, sizeof sa);
+    sa.noacc = S->pass_noacc ? 1 : 0; sa.yadd = S->pass_yadd;
     // XCD-contiguous tile order (k_schur_s): bit 0 = y passes, bit 1 = z passes; -1 (default) = the y passes of meshes in the streaming
     // regime -- the 8 x tiles of a row set then run on one XCD back to back (256^3: y 133 -> 123 us, 501 -> 493 us per CG iteration;
     // z passes lose 10 us with it; neutral to -0.5 % at 96^3 ... 192^3)
@@ -1240,9 +1252,16 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
         const int last = d == dim - 1;
         if (d == 2 && any_if) HIPCHK(hipStreamWaitEvent(T->stream, T->ev_xchg, 0));
         if (prof) prof_begin(T, d, &a, &b);
+        // x || y (slab teams, RT0-P0, slabs small enough not to fill the chip): fork after the endpoint pass -- the new p is complete --,
+        // the y pass of every local slab on y_stream into d_qy, join before the accumulation pass, which adds d_qy
+        const bool xy = dim == 3 && any_if && T->opt_xy_overlap && T->slabs[0]->nb == 0 && T->y_stream && !prof;
+        bool xy_all = xy; if (xy) for (auto *X : T->slabs) xy_all = xy_all && X->N <= T->xy_overlap_max_cells && !chunk_plan(X, 1).ok;
+        if (d == 0 && xy_all) { HIPCHK(hipEventRecord(T->ev_fork, T->stream)); HIPCHK(hipStreamWaitEvent(T->y_stream, T->ev_fork, 0)); }
+        if (d == 2 && xy_all) { HIPCHK(hipEventRecord(T->ev_join, T->y_stream)); HIPCHK(hipStreamWaitEvent(T->stream, T->ev_join, 0)); }
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i];
             const Geom G = make_geom(S);
+            if (xy_all && !S->d_qy) NFCHK(dalloc(&S->d_qy, S->nphi));
             {
                 double *part = (want_dot && (last || split)) ? T->d_partials + i * T->slab_cap + totals[i] : nullptr;
                 const ModeArgs ma = mode_args(S, g, d, 0, xs[i], ys[i]);     // mode 0; the kernels derive the others (ModeTab)
@@ -1250,7 +1269,15 @@ static int team_schur_apply(nf_team *T, int g, const std::vector<const double *>
                 S->zw_dot = split;
                 if (d == 0) NFCHK(launch_x(S, g, ma, G, last || split, part, cg, &np));
                 else if (d == 2 && (S->if_lo || S->if_hi)) {
-                    NFCHK(launch_s(S, 2, g, ma, G, last, part, cg, &np, 2));
+                    S->pass_yadd = xy_all ? S->d_qy : nullptr;
+                    const int rz = launch_s(S, 2, g, ma, G, last, part, cg, &np, 2);
+                    S->pass_yadd = nullptr;
+                    NFCHK(rz);
+                } else if (d == 1 && xy_all) {
+                    S->pass_stream = T->y_stream; S->pass_noacc = true;
+                    const int ry = launch_s(S, 1, g, mode_args(S, g, 1, 0, xs[i], S->d_qy), G, 0, nullptr, cg, &np, 0);
+                    S->pass_stream = nullptr; S->pass_noacc = false;
+                    NFCHK(ry);
                 } else NFCHK(launch_s(S, d, g, ma, G, last || split, part, cg, &np, 0));
                 S->zw_dot = false;
                 if (part) totals[i] += np;
@@ -2928,6 +2955,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
     else if (!strcmp(key, "vec_reduce")) T->opt_vec_reduce = value != 0;
+    else if (!strcmp(key, "xy_overlap")) T->opt_xy_overlap = value != 0;
+    else if (!strcmp(key, "xy_overlap_max_cells")) T->xy_overlap_max_cells = std::max(0L, value);
     else if (!strcmp(key, "split_dot")) T->opt_split_dot = (int)std::max(0L, std::min(2L, value));   // 0 never, 1 where a chunked pass runs, 2 always (big undivided RT0-P0 meshes)
     else if (!strcmp(key, "x_two_phase")) T->opt_x_p2 = value < 0 ? -1 : (value > 0 ? 1 : 0);
     else if (!strcmp(key, "s_long")) T->opt_s_long = value < 0 ? -1 : (value > 0 ? 1 : 0);

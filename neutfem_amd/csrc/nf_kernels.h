@@ -841,6 +841,9 @@ struct SlabArgs {
     // both sides of an interface, so the two copies agree bitwise
     int fold; const double *rlo, *rhi, *sinv_lo, *sinv_hi;
     int wsmin;                                // segments from which the wavefront scan of the summaries replaces the serial loops (0: default 64)
+    // x || y on small slabs (team_schur_apply): the y pass runs beside the x pass on a second stream and stores its increment alone
+    // (noacc) into a vector of its own; the accumulation pass of the z lines adds that vector (yadd) to y on the way
+    int noacc; const double *yadd;
     const double *alo, *ahi, *ulo, *uhi;      // per line
     double *clo, *chi;                        // per line (mode 1 outputs)
     double *jz;                               // mode 3: J = -u on the slab's own z faces [((face) * nx * ny + line) * nfa + amode] (Sol_J_, src/solvers.cpp:228)
@@ -1046,7 +1049,11 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     if (act) { sA2[si] = Q; sB2[si] = lu; }
     // y is only needed by the output stage: issue its loads here so they fly during the barrier + backward scan
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { const int c = c0 + i; yo[i] = (acc && valid && c < n && wr) ? ldg<NT>(y + base + (long)c * sl) : 0.0; }
+    for (int i = 0; i < SEG; ++i) {
+        const int c = c0 + i; const bool ok = acc && valid && c < n && wr;
+        yo[i] = ok ? ldg<NT>(y + base + (long)c * sl) : 0.0;
+        if (SLAB && NB == 0 && sa.yadd) yo[i] += ok ? sa.yadd[base + (long)c * sl] : 0.0;     // same order on every cell: (y_x + y_y) + z part
+    }
     double y1o[NB > 0 ? SEG : 1], y2o[NB > 1 ? SEG : 1];
     if (NB > 0) {
 #pragma unroll
@@ -1164,7 +1171,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             if (sa.mode == 1) sa.clo[lm] = -(NB == 0 ? x[edge_lo] : xe_lo) - a_lo * ulo;
             else {
                 const double u_lo = sa.fold ? (sa.rlo[lm] + sa.clo[lm]) * sa.sinv_lo[lineid] : sa.ulo[lm];
-                const double xe = x[edge_lo]; const double yv = y[edge_lo] + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv;
+                const double xe = x[edge_lo]; const double yv = (y[edge_lo] + ((NB == 0 && sa.yadd) ? sa.yadd[edge_lo] : 0.0)) + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv;
                 if (NB > 0) {                                    // bubbles of the edge cell: faces (separator, first chain face)
                     const double ice = ma.D[edge_lo] / geom_factor(G, DIR, ix, (int)by, 0);
 #pragma unroll
@@ -1185,7 +1192,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             if (sa.mode == 1) sa.chi[lm] = (NB == 0 ? x[edge_hi] : xe_hi) - a_hi * ulast;
             else {
                 const double u_hi = sa.fold ? (sa.chi[lm] + sa.rhi[lm]) * sa.sinv_hi[lineid] : sa.uhi[lm];
-                const double xe = x[edge_hi]; const double yv = y[edge_hi] + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv;
+                const double xe = x[edge_hi]; const double yv = (y[edge_hi] + ((NB == 0 && sa.yadd) ? sa.yadd[edge_hi] : 0.0)) + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv;
                 if (NB > 0) {                                    // faces (last chain face, separator)
                     const int fsz = sa.if_lo ? 1 : 0;
                     const double ice = ma.D[edge_hi] / geom_factor(G, DIR, ix, (int)by, fsz + n);
@@ -1232,7 +1239,7 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
     }
     static_assert(!ZW || (!SLAB && NB == 0), "the z.w form of the dot product is for plain RT0-P0 lines");
     const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF, NTS, NoMid, ZW>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
-                                                            (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, true);
+                                                            (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, !(!SLAB && NB == 0 && sa.noacc));
     if (SLAB && sa.mode == 3) return;
     if (last && partials) {
         double *sred = sm + 4 * TX * (NSEG + 1) + TX;
@@ -1441,7 +1448,7 @@ __global__ __launch_bounds__(512) void k_apply3(ModeArgs max0, ModeArgs may0, Mo
         const int r = b < (unsigned)(A.nbx + A.nby) ? 0 : 1;
         const unsigned t = b - A.nbx - (r ? A.nby : 0);
         const unsigned bx = t % A.gx[r], by = (t / A.gx[r]) % A.gy[r], bz = t / (A.gx[r] * A.gy[r]);
-        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = sa.wsmin = sa.fold = 0; sa.alo = sa.ahi = sa.ulo = sa.uhi = sa.rlo = sa.rhi = sa.sinv_lo = sa.sinv_hi = nullptr; sa.clo = sa.chi = sa.jz = sa.jzb = nullptr; sa.nfa = 1; sa.ni = 0;
+        SlabArgs sa; sa.if_lo = sa.if_hi = sa.mode = sa.xcd = sa.wsmin = sa.fold = sa.noacc = 0; sa.yadd = nullptr; sa.alo = sa.ahi = sa.ulo = sa.uhi = sa.rlo = sa.rhi = sa.sinv_lo = sa.sinv_hi = nullptr; sa.clo = sa.chi = sa.jz = sa.jzb = nullptr; sa.nfa = 1; sa.ni = 0;
         if (r == 0) {
             const ModeArgs ma = select_mode(may0, mty, bz, NB + 1);
             dot = schur_s_tile<SEG, 1, false, NB>(ma, G, Ly, DRy, D0y, A.n[0], A.sl[0], A.ostride[0], nx, A.TX[0], A.NSEG[0], bx, by, bz, A.gy[0],
@@ -2043,7 +2050,7 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
     double *sred = sm + scr + 64;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
     const int ng = A.ng; const long N = A.N, NP = A.nphi, NT = NP * ng;
-    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = 0; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
+    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = sa0.noacc = 0; sa0.yadd = nullptr; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
     // vectors and factors that fit are kept in LDS behind the scratch area (ResidentArgs::lds_mask); the rest stays in global memory
     double *lds = sm + scr + 64 + 16;
     long lo = 0;
