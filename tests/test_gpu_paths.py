@@ -45,6 +45,8 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     o = make_oracle(inp, rt, p); o.set_tol(*tol); ko = o.SolveKeff()
     res = {}
     for name, opts, path in PATHS:
+        if name.startswith("big-") and (rt > 0 or shape[1] == 1):
+            continue                                                # split dot / chunked lines exist for RT0-P0 y / z passes only: elsewhere these options change nothing
         r = res[name] = _run(inp, rt, p, tol, opts)
         if name == "resident-scans" and shape[0] > 128:
             path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
@@ -55,6 +57,8 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     assert res["classic-streaming"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-streaming"]["phi"], res["classic"]["phi"])   # same arithmetic, other load instructions
     assert res["classic-no-host-page"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-no-host-page"]["phi"], res["classic"]["phi"])   # readback route only
     for name in ("fuse3", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
+        if name not in res:
+            continue
         assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
         assert rel_l2(res[name]["phi"], res["classic"]["phi"]) < 1e-9
 
@@ -71,6 +75,8 @@ def test_paths_fixed_work_histories(shape, rt, ng):
     for name, opts, path in PATHS:
         if name == "resident-scans" and shape[0] > 128:
             path = 0
+        if name.startswith("big-") and (rt > 0 or shape[1] == 1):
+            continue
         r = _run(inp, rt, rt, tol, opts)
         assert r["path"] == path and r["n"] == 6, (name, r["path"], r["n"])
         np.testing.assert_allclose(r["hk"], ho["k"], rtol=1e-9, err_msg=name)
