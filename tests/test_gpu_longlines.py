@@ -109,3 +109,31 @@ def test_solve_keff_c5_generator_512_cell_lines():
         if tol[4] == 50:
             assert np.array_equal(s.history()["cg"], o.history()["cg"])
     s.close()
+
+
+def test_full_size_512cube_properties():
+    """BASELINE config 4 at full size (synthetic checkerboard 512^3, here 2 of its groups: 134 M cells, 512-cell lines in all three
+    directions, the chunked y / z passes with 32 columns x 1024 threads), where the oracle is not run: size-independent properties of
+    S_g -- linear, symmetric, positive -- through the same nf_schur_apply the bench times, a CG solve that really leaves
+    |S x - b| <= tol |b| (checked with a separate apply; inside CG the split dot product is in use), and the same apply against the
+    one-chunk kernels (s_long = 0) at 1e-13."""
+    from bench import make_solver
+    from neutfem_amd import cases
+    s = make_solver(cases.synthetic_checkerboard(512, 2), 0)
+    n = s.n_phi
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    for g in range(2):
+        Sx, Sy = s.schur_apply(g, x), s.schur_apply(g, y)
+        Sxy = s.schur_apply(g, 2.0 * x - 3.0 * y)
+        assert rel_l2(Sxy, 2.0 * Sx - 3.0 * Sy) < 1e-12
+        assert abs(y @ Sx - x @ Sy) <= 1e-10 * abs(y @ Sx)
+        assert x @ Sx > 0
+        del Sy, Sxy
+    b = np.abs(y)
+    xs, its, res = s.solve_group(1, b, 1e-5, 3000)
+    assert 0 < its < 3000 and res < 1e-5
+    assert np.linalg.norm(s.schur_apply(1, xs) - b) < 1.05e-5 * np.linalg.norm(b)
+    s.set_option("s_long", 0)
+    assert rel_l2(s.schur_apply(1, x), Sx) < 1e-13                 # Sx = group 1 from the loop above
+    s.close()
