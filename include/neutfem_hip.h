@@ -121,7 +121,7 @@ int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_ou
  * (the `it` of the loop at src/NeutFEM.cpp:1694).  May be called from another thread while nf_solve_keff runs -- the watchdog
  * of a multi-rank job tells a slow solve from one whose peers are gone.  On a multi-rank team a rank that fails inside a solve
  * makes every rank return (the failing one with its own code, the others with NF_ERR_REMOTE); a collective that does not complete
- * within NEUTFEM_COMM_TIMEOUT_S seconds (default 600) returns NF_ERR_COMM. */
+ * within NEUTFEM_COMM_TIMEOUT_S seconds (default 120) returns NF_ERR_COMM. */
 int nf_progress(nf_handle h, long *outers_done);
 
 /* CMFD acceleration (src/NeutFEM.cpp:662-1017, include/NeutFEM.hpp:119-143,232-235): NeutFEM::InitializeCMFD

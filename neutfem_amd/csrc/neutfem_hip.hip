@@ -131,7 +131,7 @@ struct nf_team {
     int xchg_in_apply = 0;          // interface exchanges issued since the current Schur apply began
     long cg_iter_total = 0;         // CG iterations launched since the team was created (NEUTFEM_INJECT_FAIL=<rank>:<iteration>)
     int inject_rank = -1; long inject_iter = -1;
-    double comm_timeout_s = 600.0;  // multi-rank teams: a stream that does not drain for this long means a peer is gone (NEUTFEM_COMM_TIMEOUT_S)
+    double comm_timeout_s = 120.0;  // multi-rank teams: a stream that does not drain for this long means a peer is gone (NEUTFEM_COMM_TIMEOUT_S)
     volatile long outers_done = 0;  // completed outer iterations of the running / last SolveKeff (bench.py's watchdog polls it from another thread)
     bool linked_ready = false;      // separator diagonals exchanged
     int sep_sweeps = 0;             // Jacobi sweeps on the separator system (0: slabs thick enough for it to be diagonal to rounding)
