@@ -32,4 +32,6 @@ def install_compat(with_shims=False):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libneutfem_hip.so")
+    """libneutfem_hip.so of this tree; NEUTFEM_HIP_LIB names another build of the same C ABI (A/B runs of two kernel versions in
+    profiles/tools/: the file must exist, there is no fallback)"""
+    return os.environ.get("NEUTFEM_HIP_LIB") or os.path.join(_HERE, "lib", "libneutfem_hip.so")

@@ -1832,6 +1832,14 @@ __device__ __forceinline__ double block_total_1b(double v, double *sred, int par
 // (LDS instructions carry a 16-bit byte offset).  The n - 1 cells that have an upper neighbour go in unpredicated pieces of 8 / 4 / 2 / 1
 // cells (a predicated or clamped load costs more instructions than the arithmetic), the last cell on its own.
 typedef __attribute__((address_space(3))) double lds_f64;      // explicit LDS pointers: ds_read / ds_write with 32-bit addresses, not flat accesses
+// Three per-direction values as named members.  A local array T v[3] that is indexed by a run-time direction anywhere (or through a chain
+// d == 0 ? v[0] : ..., which the optimiser folds back into v[d]) is kept in scratch memory for the whole kernel, and every use inside the
+// CG loop becomes a scratch load in front of the dependent LDS access.
+template <class T> struct Tri {
+    T a, b, c;
+    __device__ __forceinline__ T operator[](int d) const { return d == 0 ? a : d == 1 ? b : c; }
+    __device__ __forceinline__ void set(int d, T v) { if (d == 0) a = v; else if (d == 1) b = v; else c = v; }
+};
 template <int CH, int PITCH>
 __device__ __forceinline__ void serial_fwd(const lds_f64 *&xp, lds_f64 *&bp, int sl, double &z, double &xc)
 {
@@ -2066,16 +2074,18 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
     // padded cells tid + 512 k for the whole solve and keeps their r, x_sol and C diagonal in registers; cells of the padding and beyond
     // the mesh hold zeros everywhere, so nothing below is predicated.
     constexpr int KC = SERIAL ? PITCH / 512 : 1;
-    lds_f64 *lp = nullptr, *lb[3] = { nullptr, nullptr, nullptr }; const lds_f64 *lD[3] = { nullptr, nullptr, nullptr };
-    lds_f64 *lDm[3] = { nullptr, nullptr, nullptr }, *lDr[3] = { nullptr, nullptr, nullptr };   // 1 / d'_k and 1 / d^_n per line (two-sided sweeps)
+    lds_f64 *lp = nullptr; Tri<lds_f64 *> lb = { nullptr, nullptr, nullptr }; Tri<const lds_f64 *> lD = { nullptr, nullptr, nullptr };
+    Tri<lds_f64 *> lDm = { nullptr, nullptr, nullptr }, lDr = { nullptr, nullptr, nullptr };   // 1 / d'_k and 1 / d^_n per line (two-sided sweeps)
     int gi[KC], nxp = 0;
     if (SERIAL) {
         nxp = A.G.nx | 1;
         lp = (lds_f64 *)lds; lo = PITCH;
-        for (int d = 0; d < A.dim; ++d) { lb[d] = (lds_f64 *)(lds + lo); lo += 3 * PITCH; }
-        for (int d = 0; d < A.dim; ++d) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (d < A.dim) { lb.set(d, (lds_f64 *)(lds + lo)); lo += 3 * PITCH; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (d < A.dim) {
             const long nl2 = (A.nlines[d] + 1) & ~1L;
-            lD[d] = (const lds_f64 *)(lds + lo); lDm[d] = (lds_f64 *)(lds + lo + nl2); lDr[d] = (lds_f64 *)(lds + lo + 2 * nl2); lo += 3 * nl2;
+            lD.set(d, (const lds_f64 *)(lds + lo)); lDm.set(d, (lds_f64 *)(lds + lo + nl2)); lDr.set(d, (lds_f64 *)(lds + lo + 2 * nl2)); lo += 3 * nl2;
         }
         const int Np = nxp * A.G.ny * A.G.nz;
 #pragma unroll
@@ -2083,15 +2093,16 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
             const int ip = tid + k * 512, row = ip / nxp, ix = ip - row * nxp;
             gi[k] = (ip < Np && ix < A.G.nx) ? row * A.G.nx + ix : -1;
             lp[ip] = 0.0;
-            for (int d = 0; d < A.dim; ++d) lb[d][2 * PITCH + ip] = 0.0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) if (d < A.dim) lb[d][2 * PITCH + ip] = 0.0;
         }
     }
     // Higher orders: DOF j = moment * PC + padded cell; p and one contribution vector per direction (nloc PC each), {L, 1/d} per
     // direction (PC each), first pivots; small tables (moment indices, T_a, diagonal factors) in LDS because a dynamically indexed
     // kernel argument would move the whole argument struct to scratch.  Every thread owns the DOFs tid + 512 k, k < KD.
     constexpr int KD = SERH ? 10 : 1;
-    lds_f64 *hp = nullptr, *hc[3] = { nullptr, nullptr, nullptr }, *hL[3] = { nullptr, nullptr, nullptr }, *hD[3] = { nullptr, nullptr, nullptr };
-    lds_f64 *hDm[3] = { nullptr, nullptr, nullptr }, *hDr[3] = { nullptr, nullptr, nullptr };
+    lds_f64 *hp = nullptr; Tri<lds_f64 *> hc = { nullptr, nullptr, nullptr }, hL = { nullptr, nullptr, nullptr }, hD = { nullptr, nullptr, nullptr };
+    Tri<lds_f64 *> hDm = { nullptr, nullptr, nullptr }, hDr = { nullptr, nullptr, nullptr };
     lds_f64 *tTa = nullptr, *tDg = nullptr; __attribute__((address_space(3))) int *tMom = nullptr;
     int gj[KD], hPC = 0, hNPp = 0, hNp = 0;
     if (SERH) {
@@ -2099,11 +2110,15 @@ __global__ __launch_bounds__(512) void k_resident_keff(ResidentArgs A)
         const int nloc = (int)(NP / N); hNPp = nloc * hPC;
         tTa = (lds_f64 *)lds; tDg = tTa + 32; tMom = (__attribute__((address_space(3))) int *)(tDg + 96); lo = 32 + 96 + 48;
         hp = (lds_f64 *)(lds + lo); lo += hNPp;
-        for (int d = 0; d < A.dim; ++d) { hc[d] = (lds_f64 *)(lds + lo); lo += hNPp; }
-        for (int d = 0; d < A.dim; ++d) { hL[d] = (lds_f64 *)(lds + lo); lo += 2 * hPC; }
-        for (int d = 0; d < A.dim; ++d) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (d < A.dim) { hc.set(d, (lds_f64 *)(lds + lo)); lo += hNPp; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (d < A.dim) { hL.set(d, (lds_f64 *)(lds + lo)); lo += 2 * hPC; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (d < A.dim) {
             const long nl2 = (A.nlines[d] + 1) & ~1L;
-            hD[d] = (lds_f64 *)(lds + lo); hDm[d] = hD[d] + nl2; hDr[d] = hD[d] + 2 * nl2; lo += 3 * nl2;
+            lds_f64 *const b_ = (lds_f64 *)(lds + lo);
+            hD.set(d, b_); hDm.set(d, b_ + nl2); hDr.set(d, b_ + 2 * nl2); lo += 3 * nl2;
         }
         if (tid < 27) { const int d = tid / 9, m = tid % 9; tTa[tid] = A.mt[d].n > 1 ? A.mt[d].Ta[m] : A.ma[d].Ta; }
         if (tid < 81) { tDg[tid] = A.diagc[tid / 3][tid % 3]; tMom[tid] = A.mom[tid / 27][(tid / 3) % 9][tid % 3]; }
