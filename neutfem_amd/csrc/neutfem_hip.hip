@@ -162,6 +162,10 @@ struct nf_team {
     // fused-direction CG (two launches per iteration) up to this many cells.  Measured crossover against the four-launch lean path after
     // the round-2 latency work: 64^3 19.1 vs 27.2 us per CG iteration, 80^3 39.1 vs 34.5, 128^3 77.7 vs 70.9, 160^3 221 vs 150
     int opt_fuse3 = 1; long fuse3_max_cells = 400000;
+    // whole CG solve in one launch on the workgroups of one XCD (k_cg_xcd): RT0-P0 meshes between the one-workgroup resident kernel and
+    // xcd_max_cells.  One XCD has an eighth of the chip's compute units and L2 (4 MiB): beyond that the launch path wins back.
+    int opt_cgx = 1, xcd_id = 0, xcd_groups = 32, last_xcd = 0; long xcd_min_cells = 2000, xcd_max_cells = 28000, xcd_solves = 0, xcd_refused = 0;
+    XcdState *d_xcd = nullptr; double *d_xpart = nullptr;
     int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, opt_resident_two_sided = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
     int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
@@ -362,6 +366,8 @@ static void team_free(nf_team *T)
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
+    if (T->d_xcd) (void)hipFree(T->d_xcd);
+    dfree(T->d_xpart);
     dfree(T->d_partials); dfree(T->d_cg); dfree(T->d_out); dfree(T->d_red); dfree(T->d_errsrc); dfree(T->d_vec); dfree(T->d_ost); dfree(T->d_hist); dfree(T->d_hist_cg); dfree(T->d_rout);
     if (T->h_pub) (void)hipHostFree(T->h_pub);
     if (T->comm_stream) { (void)hipStreamSynchronize(T->comm_stream); (void)hipStreamDestroy(T->comm_stream); }
@@ -618,7 +624,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("rt_order", S->k); K("p_order", S->m); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce);
+    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce); K("last_xcd", T->last_xcd); K("xcd_solves", T->xcd_solves); K("xcd_refused", T->xcd_refused);
 #undef K
     return -1;
 }
@@ -1397,6 +1403,60 @@ static int launch_apply3(nf_solver *S, int g, const Fuse3Plan &P, const double *
     return NF_OK;
 }
 
+// ---- whole CG solve on one XCD (k_cg_xcd) ---------------------------------------------------------
+// CgScalars hold the outcome of FIN_RHS, r = p = rhs, x = 0.  One launch; the kernel publishes the final scalars to the host itself.
+static bool xcd_eligible(const nf_team *T, const nf_solver *S, const Fuse3Plan &P)
+{
+    if (!T->opt_cgx || !P.ok || S->nb != 0 || S->nloc != 1 || n_modes(S) != 1 || T->profile) return false;   // one unknown per cell (P0 flux)
+    if (S->N < T->xcd_min_cells || S->N > T->xcd_max_cells) return false;
+    for (int r = 0; r < 2; ++r) if (S->dim >= r + 2 && (P.A.NSEG[r] >= 64 || P.A.TX[r] * P.A.NSEG[r] > 448)) return false;   // no wavefront scan in the packed tiles; a tile fits beside the other roles
+    return S->nx <= 128;                                          // x lines: at most two chunks per lane (128 VGPRs at 1024 threads)
+}
+static int launch_cg_xcd(nf_solver *S, int g, const Fuse3Plan &P, double *xsol, unsigned long long seq)
+{
+    nf_team *T = S->team; hipStream_t st = T->stream;
+    const long N = S->N;
+    if (!T->d_xcd) { HIPCHK(hipMalloc((void **)&T->d_xcd, sizeof(XcdState))); NFCHK(dalloc(&T->d_xpart, 256)); HIPCHK(hipMemset(T->d_xpart, 0, 256 * sizeof(double))); }
+    HIPCHK(hipMemsetAsync(T->d_xcd, 0, sizeof(XcdState), st));
+    XcdArgs A; memset(&A, 0, sizeof A);
+    A.G = make_geom(S);
+    double *qd[3] = { S->d_q, S->d_qy, S->d_qz };
+    for (int d = 0; d < 3; ++d) {
+        const int dd = d < S->dim ? d : 0;
+        A.ma[d] = mode_args(S, g, dd, 0, S->d_p, qd[dd]);
+        A.L[d] = S->d_L[dd] + g * N; A.DR[d] = S->d_DR[dd] + g * N; A.D0[d] = S->d_D0[dd] + g * S->nlines[dd]; A.q[d] = qd[dd];
+    }
+    A.nx = S->nx; A.ny = S->ny; A.dim = S->dim; A.nlines_x = S->nlines[0]; A.N = S->nphi;
+    // x lines: few wavefronts matter more here than short scans (the roles share the 16 wavefronts of a workgroup, and a second round
+    // costs a whole memory round trip): two chunks per lane from 33 cells on -- 38 cells = 16 lanes x 2 cells x 2 chunks, four lines
+    // per wavefront, where the launch path takes 32 lanes and two lines
+    int lanes = (S->nx + 1) / 2, lpl_log2 = 0;
+    while ((1 << lpl_log2) < lanes && lpl_log2 < 5) ++lpl_log2;
+    int nch = (lanes + (1 << lpl_log2) - 1) >> lpl_log2;
+    if (nch == 1 && lpl_log2 == 5) {
+        // 32 lanes, one chunk (the shorter chain) if the three roles of a workgroup still fit its wavefronts in one round
+        const int Pn = T->xcd_groups, tasks = (int)((S->nlines[0] + 1) / 2);
+        int waves = (tasks + Pn - 1) / Pn;
+        for (int r = 0; r < 2; ++r) if (S->dim >= r + 2) waves += (((P.A.gx[r] * P.A.gy[r] + Pn - 1) / Pn) * P.A.TX[r] * P.A.NSEG[r] + 63) / 64;
+        if (waves > XCD_THREADS / 64) { lpl_log2 = 4; nch = 2; }
+    }
+    if (nch > 2) return fail(NF_ERR_STATE, "k_cg_xcd: x lines of %d cells", S->nx);
+    A.lpl_log2 = lpl_log2; A.ntask_x = (int)((S->nlines[0] + (64 >> lpl_log2) - 1) / (64 >> lpl_log2));
+    for (int r = 0; r < 2; ++r) { A.n[r] = P.A.n[r]; A.TX[r] = P.A.TX[r]; A.NSEG[r] = P.A.NSEG[r]; A.gx[r] = P.A.gx[r]; A.gy[r] = P.A.gy[r]; A.sl[r] = P.A.sl[r]; A.ostride[r] = P.A.ostride[r]; }
+    if (S->dim < 2) { A.TX[0] = A.NSEG[0] = 1; } if (S->dim < 3) { A.TX[1] = A.NSEG[1] = 1; }
+    A.pA = S->d_p; A.pB = S->d_p2; A.r = S->d_r; A.xsol = xsol;
+    A.cg = T->d_cg; A.part = T->d_xpart; A.st = T->d_xcd; A.hp = T->d_pub; A.seq = seq; A.xcc = T->xcd_id;
+    const size_t lds = (size_t)(5 * 1024 + 64 + 32) * sizeof(double);
+    const unsigned G = 8u * (unsigned)T->xcd_groups;
+#define NF_XCD(NCHV, VECV) do { if (!lds_opt_in((const void *)k_cg_xcd<NCHV, VECV>, lds)) return fail(NF_ERR_HIP, "k_cg_xcd: %zu bytes of LDS refused", lds); \
+        hipLaunchKernelGGL((k_cg_xcd<NCHV, VECV>), dim3(G), dim3(XCD_THREADS), lds, st, A); } while (0)
+    if (nch == 1) { if (P.vec) NF_XCD(1, true); else NF_XCD(1, false); }
+    else { if (P.vec) NF_XCD(2, true); else NF_XCD(2, false); }
+#undef NF_XCD
+    HIPCHK(hipGetLastError());
+    return NF_OK;
+}
+
 // ---- CG (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636) -----------------------------
 // rhs / x: per-slab pointers
 // inited: k_group_rhs has already written x = 0, r = p = rhs and the |rhs|^2 partials (one launch less per group solve)
@@ -1441,6 +1501,34 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         if (!S0->d_p2) NFCHK(dalloc(&S0->d_p2, S0->nphi));
         if (S0->dim >= 2 && !S0->d_qy) NFCHK(dalloc(&S0->d_qy, S0->nphi));
         if (S0->dim == 3 && !S0->d_qz) NFCHK(dalloc(&S0->d_qz, S0->nphi));
+    }
+    T->last_xcd = 0;
+    if (f3.ok && xcd_eligible(T, S0, f3) && pub_ready(T)) {
+        // the whole solve in one launch on one XCD (k_cg_xcd); the kernel hands the final scalars to the host itself
+        const unsigned long long seq = ++T->pub_seq;
+        for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = CgFuse{ nullptr, nullptr, nullptr };
+        NFCHK(launch_cg_xcd(S0, g, f3, x[0], seq));
+        NFCHK(pub_wait(T, seq, &sc, nullptr, 0));
+        if (sc.err == 4) {
+            T->opt_cgx = 0;
+            return fail(NF_ERR_HIP, "XCD-local CG (k_cg_xcd): a grid barrier timed out in the middle of the solve of group %d (a participant was lost); "
+                                    "the path is now off for this solver", g);
+        }
+        if (sc.err != 3) {
+            T->last_xcd = 1; ++T->xcd_solves;
+            HIPCHK(hipGetLastError());
+            if (!std::isfinite(sc.rr)) return fail(NF_ERR_NUMERIC, "CG produced a non-finite residual (group %d)", g);
+            T->last_its[g] = sc.its;
+            if (its_out) *its_out = sc.its;
+            if (res_out) *res_out = sc.rhs_norm > 0 ? std::sqrt(sc.rr) / sc.rhs_norm : 0.0;
+            return NF_OK;
+        }
+        // the workgroups did not assemble (nothing placed on the XCD, or it is busy): no vector has been touched -- this solve and the
+        // following ones of this solver go through the launch path
+        T->opt_cgx = 0; ++T->xcd_refused;
+        for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
+        NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
+        memset(&sc, 0, sizeof sc);
     }
     // A local failure on a multi-rank team (a refused launch, a failed HIP call) must not end this rank's part of the schedule: the
     // other ranks are about to wait in the collectives of this batch.  The rank raises its error flag (it rides in every reduction
@@ -1939,7 +2027,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
         CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
-        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_cgx = T->opt_cgx; CT->xcd_min_cells = T->xcd_min_cells; CT->xcd_max_cells = T->xcd_max_cells; CT->xcd_id = T->xcd_id; CT->xcd_groups = T->xcd_groups; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
     double kc = 1.0; int nout = 0;
@@ -2982,6 +3070,11 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "resident_serial_max_dofs")) T->resident_serial_max_dofs = value;
     else if (!strcmp(key, "direct_max_dofs")) T->direct_max_dofs = std::max(0L, std::min(8192L, value));
     else if (!strcmp(key, "cg_fuse3")) T->opt_fuse3 = value != 0;
+    else if (!strcmp(key, "cg_xcd")) T->opt_cgx = value != 0;
+    else if (!strcmp(key, "cg_xcd_min_cells")) T->xcd_min_cells = value;
+    else if (!strcmp(key, "cg_xcd_max_cells")) T->xcd_max_cells = value;
+    else if (!strcmp(key, "cg_xcd_id")) T->xcd_id = (int)(value & 15);   // 8..15: no such XCD -- nobody registers, the solve falls back (tests)
+    else if (!strcmp(key, "cg_xcd_groups")) T->xcd_groups = (int)std::max<long>(1, std::min<long>(value, 64));
     else if (!strcmp(key, "cg_fuse3_max_cells")) T->fuse3_max_cells = value;
     else if (!strcmp(key, "cg_lean_grid")) T->opt_lean_grid = (int)std::max(1L, std::min(1024L, value));
     else return fail(NF_ERR_ARG, "nf_set_option: unknown key %s", key);
@@ -3016,3 +3109,14 @@ int nf_memcpy_d2h(nf_handle S, void *dst, const void *src, size_t bytes)
 }
 int nf_synchronize(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); HIPCHK(hipSetDevice(S->device)); HIPCHK(hipStreamSynchronize(S->team->stream)); HIPCHK(hipDeviceSynchronize()); return NF_OK; }
 void *nf_stream(nf_handle S) { return S ? (void *)S->team->stream : nullptr; }
+
+// diagnostic (not part of the C ABI): the partial / stamp buffer of k_cg_xcd (doubles 128.. hold cycle stamps in -DNF_XSTAMPS builds)
+extern "C" int nf_debug_xcd_buffer(void *h, double *out, int n, int coarse)
+{
+    nf_solver *S = (nf_solver *)h; if (!S || !S->team) return NF_ERR_ARG;
+    nf_team *T = S->team;
+    (void)coarse;
+    if (!T->d_xpart) { for (int i = 0; i < n; ++i) out[i] = 0.0; return NF_OK; }
+    HIPCHK(hipMemcpy(out, T->d_xpart, sizeof(double) * std::min(n, 256), hipMemcpyDeviceToHost));
+    return NF_OK;
+}

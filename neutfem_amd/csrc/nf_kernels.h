@@ -860,7 +860,9 @@ struct SlabArgs {
 // A = L D L^T is T_a sum_faces z_f^2 / d_f = T_a sum z_f w_f, and both factors are at hand in the forward sweep.  The x pass then
 // contributes x.(C x + S_x x) and the consumer adds the three sets of partials: the backward half of a y / z pass needs no x at all
 // (eight doubles fewer live through the scans, and the chunked long-line pass has nothing to re-read for its parked chunk).
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid, bool ZW = false>   // NTS: streaming loads in a slab variant
+// XC (k_cg_xcd: the producers of x and r are other workgroups of the SAME launch on the same XCD): every load of x and r bypasses the
+// compute unit's L1 -- the overlap cell too
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid, bool ZW = false, bool XC = false>   // NTS: streaming loads in a slab variant
 __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                                                unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
@@ -944,7 +946,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
         // the overlap cell (i == SEG) is the next segment's first: keep that line for it (see k_schur_c on why this is not a ternary on i)
-        if (i < SEG) xv[i] = ok ? ldg<NT>(x + a) : 0.0; else xv[i] = ok ? x[a] : 0.0;
+        if (i < SEG || XC) xv[i] = ok ? ldg<NT>(x + a) : 0.0; else xv[i] = ok ? x[a] : 0.0;
         if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : ldg<NT>(x + a + roff)) : 0.0;
         if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
         if (i < SEG) Lv[i] = ok ? ldg<NT>(L + a) : 0.0; else Lv[i] = ok ? L[a] : 0.0;
@@ -1498,6 +1500,205 @@ __global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, con
     }
     s = block_sum(s, sred);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A whole CG solve (src/solvers.cpp:577-636) of a mid-size undivided RT0-P0 mesh in ONE launch, on the workgroups of ONE XCD.
+// Between the one-workgroup resident kernel (a few thousand unknowns) and the meshes that fill the chip, a CG iteration is two
+// dependent launches (k_apply3, k_cg_rupdate3) whose cost is the launch boundary itself: 7.2 + 4.3 us of kernels that mostly wait for
+// their first loads (L2 was written back at the boundary) plus 3.7 us of gap, on IAEA-3D 38x38x19.  The two reductions of an
+// iteration need two grid-wide synchronisations; inside one launch those are barriers on a counter, and a barrier among the 32 compute
+// units that share one L2 costs 0.93 us (profiles/tools/xcd_barrier.hip, profiles/r03_w_xcd_barrier.txt: two barriers + a 4 KB
+// hand-off per workgroup 1.86 us with L1-bypassing loads, 3.7 us with an agent acquire per barrier, 8.9 us with release + acquire).
+//   * 8 W workgroups are launched; a workgroup reads its XCD from HW_REG_XCC_ID, registers, and leaves unless it sits on XCD `xcc`.
+//     Placement is observed, not assumed: the P workgroups that registered share the work, whatever P is (round-robin dispatch
+//     gives W).  All participants share one L2, so a store that has been acknowledged (s_waitcnt vmcnt(0)) is visible to a load
+//     that bypasses the reader's L1 (non-temporal / sc1 loads: the tile functions' streaming flavour) -- no L2 write-back
+//     (buffer_wbl2), no L1 invalidate.  Uniform reads of exchanged words are explicit sc1 loads (a plain one may become a scalar
+//     load through the scalar cache, which nothing here invalidates).
+//   * every spin is bounded.  Workgroups that do not assemble (P = 0, P > 64, a start that times out: the XCD is busy with somebody
+//     else's kernel) end the launch with CgScalars::err = 3 before a single vector has been touched and the host runs the solve
+//     through the launch path; a barrier that times out in the middle of a solve (err = 4) is an error.
+//   * every workgroup derives alpha, beta and the stop tests itself from the same partial sums in the same order: control flow is
+//     uniform across workgroups without flags, and no scalar lives in memory during the solve.
+// Phase A of an iteration = what k_apply3 does (q_x = C p + X p with the deferred x_sol += alpha p, p' = r + beta p written to the
+// other buffer of the pair; q_y = Y p, q_z = Z p from p formed on the fly; p.q partials), phase B = k_cg_rupdate3.  Inside a
+// 1024-thread workgroup the three roles run side by side on different wavefronts (x: one wave-task per wave; y / z: sub-tiles of
+// TX NSEG threads packed into the role's waves; the x waves keep the two barriers of a tile company).
+// Partial sums: one per workgroup, added in workgroup order -- not the order of the launch path, so the iterates differ from it in
+// the last bits (like the resident kernel's do); every run gives the same bits.
+struct XcdState { unsigned arrived, nreg, count, timeout; };
+struct XcdArgs {
+    ModeArgs ma[3]; Geom G;
+    const double *L[3], *DR[3], *D0[3];
+    int nx, ny, dim; long nlines_x, N;
+    int ntask_x, lpl_log2;
+    int n[2], TX[2], NSEG[2], gx[2], gy[2]; long sl[2], ostride[2];   // y (0) and z (1) tiles
+    double *pA, *pB, *r, *xsol; const double *q[3];
+    CgScalars *cg; double *part;                                      // part: 2 x 64 doubles (p.q | |r|^2 partials)
+    XcdState *st; HostPub *hp; unsigned long long seq; int xcc;
+};
+__device__ __forceinline__ unsigned xld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool xcd_spin(const unsigned *p, unsigned target, unsigned *timeout)
+{
+    for (int i = 0; i < 400000; ++i) {                           // ~0.3 s: only a lost participant gets here
+        if (xld(p) >= target) return true;
+        if ((i & 1023) == 1023 && xld(timeout)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+// all threads; every wave's stores have been acknowledged by L2 before thread 0 arrives
+__device__ __forceinline__ bool xcd_barrier(XcdState *st, unsigned target, int *s_ok)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&st->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_ok = xcd_spin(&st->count, target, &st->timeout) ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+constexpr int XCD_THREADS = 768;                                 // 12 wavefronts = 3 per SIMD: 170 VGPRs (at 1024 threads the 128-VGPR budget spilled into the loop: a reload from scratch is a trip to L2 there)
+template <int NCH, bool VEC>
+__global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
+{
+    extern __shared__ double sm[];
+    __shared__ int s_i[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *const sred = sm + 5 * 1024 + 64;
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    const bool part = (int)(id & 0xf) == A.xcc;
+    if (tid == 0) {
+        s_i[0] = part ? (int)__hip_atomic_fetch_add(&A.st->nreg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        const unsigned before = __hip_atomic_fetch_add(&A.st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1 == gridDim.x && xld(&A.st->nreg) == 0) {  // the last workgroup to start, and nobody sits on the chosen XCD: say so
+            A.cg->err = 3; A.cg->done = 1;
+            if (A.hp) { A.hp->cg = *A.cg; __threadfence_system(); __hip_atomic_store(&A.hp->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+    }
+    if (!part) return;
+    if (tid == 0) { s_i[2] = xcd_spin(&A.st->arrived, gridDim.x, &A.st->timeout) ? 1 : 0; s_i[1] = (int)xld(&A.st->nreg); }
+    __syncthreads();
+    const int widx = s_i[0], P = s_i[1];
+    bool ok = s_i[2] != 0 && P <= 64;
+    const int dim = A.dim; const long N = A.N;
+    // ---- this workgroup's share and the split of its wavefronts among the roles (see the header)
+    const int Ty = A.TX[0] * A.NSEG[0], Tz = A.TX[1] * A.NSEG[1];
+    const int nty = dim >= 2 ? A.gx[0] * A.gy[0] : 0, ntz = dim == 3 ? A.gx[1] * A.gy[1] : 0;
+    const int dx = (A.ntask_x + P - 1) / P, ty = (nty + P - 1) / P, tz = (ntz + P - 1) / P;
+    int R = 1, wx = 0, wy = 0, wz = 0, cy = 0, cz = 0;
+    for (;; ++R) {
+        wx = (dx + R - 1) / R; cy = (ty + R - 1) / R; cz = (tz + R - 1) / R;
+        wy = (cy * Ty + 63) >> 6; wz = (cz * Tz + 63) >> 6;
+        if (wx + wy + wz <= XCD_THREADS / 64 || R >= 4096) break;
+    }
+    if (wx + wy + wz > XCD_THREADS / 64) ok = false;
+    const int role = wave < wx ? 0 : wave < wx + wy ? 1 : wave < wx + wy + wz ? 2 : 3;
+    // y and z tiles run the same code (RT0-P0: the direction is nothing but strides): a tile wave picks its direction's parameters once
+    const bool isz = role == 2;
+    const int sT = isz ? Tz : Ty, sC = isz ? cz : cy, sPer = isz ? tz : ty, sNt = isz ? ntz : nty;
+    const int sTX = isz ? A.TX[1] : A.TX[0], sNSEG = isz ? A.NSEG[1] : A.NSEG[0], sGx = isz ? A.gx[1] : A.gx[0], sGy = isz ? A.gy[1] : A.gy[0], sN = isz ? A.n[1] : A.n[0];
+    const long sSl = isz ? A.sl[1] : A.sl[0], sOst = isz ? A.ostride[1] : A.ostride[0];
+    const double *const sL = isz ? A.L[2] : A.L[1], *const sDR = isz ? A.DR[2] : A.DR[1], *const sD0 = isz ? A.D0[2] : A.D0[1];
+    ModeArgs ms = A.ma[0]; ms.Ta = isz ? A.ma[2].Ta : A.ma[1].Ta; ms.y[0] = isz ? A.ma[2].y[0] : A.ma[1].y[0];
+    const int sLt = tid - (isz ? wx + wy : wx) * 64, sSlot = sLt / sT, sLtid = sLt - sSlot * sT;
+    double *const sSm = sm + (isz ? cy * (4 * Ty + A.TX[0]) : 0) + ((sSlot >= 0 && sSlot < sC) ? sSlot : 0) * (4 * sT + sTX);
+    ModeArgs mx = A.ma[0];
+    SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = sa0.noacc = 0; sa0.yadd = nullptr; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
+    // ---- scalars as k_finalize(FIN_RHS) left them (a launch earlier)
+    double rr = A.cg->rr, alpha = 0.0, beta = 0.0, rr_new = A.cg->rr;
+    const double tol_sq = A.cg->tol_sq; const int maxit = A.cg->maxit;
+    int its = 0, pend = 0, err = ok ? 0 : 3;
+    unsigned nbar = 0;
+    double *const ppq = A.part, *const prr = A.part + 64;
+#ifdef NF_XSTAMPS
+    long long xs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, xt = (long long)__builtin_amdgcn_s_memrealtime();
+#define NF_XS(k) do { const long long t_ = (long long)__builtin_amdgcn_s_memrealtime(); xs[k] += t_ - xt; xt = t_; } while (0)
+#else
+#define NF_XS(k) do { } while (0)
+#endif
+    if (ok && !A.cg->done)
+        for (;;) {
+            const bool fuse = its > 0;
+            double *const pin = (its == 0 || (its & 1)) ? A.pA : A.pB, *const pout = pin == A.pA ? A.pB : A.pA;
+            const CgFuse fz = { pin, A.r, A.xsol, pout };
+            // ---- phase A: q_d = S_d p for every direction, p.q
+            double dot = 0.0;
+            for (int ro = 0; ro < R; ++ro) {
+                if (role == 1 || role == 2) {
+                    const int k = ro * sC + sSlot, t = widx * sPer + k;
+                    const bool act = sSlot < sC && k < sPer && t < sNt;
+                    const unsigned tt = act ? t : 0;
+                    ms.x[0] = pin;
+                    dot += schur_s_tile<8, 1, false, 0, true, false, NoMid, false, true>(ms, A.G, sL, sDR, sD0, sN, sSl, sOst, A.nx, sTX, sNSEG, tt % sGx, tt / sGx, 0, sGy,
+                                                                                          sLtid, act, sSm, sa0, fz, false, fuse, alpha, beta, false);
+                } else {
+                    const int k = ro * wx + wave; const long gt = (long)widx * dx + k;
+                    const bool act = role == 0 && k < dx && gt < A.ntask_x;
+                    mx.x[0] = pin;
+                    dot += schur_x_task<2, NCH, VEC, 0, NoMid, true, true>(mx, A.G, A.L[0], A.DR[0], A.D0[0], A.nx, A.ny, A.nlines_x, A.lpl_log2, 1, act ? gt : 0, lane, act,
+                                                                           fuse, alpha, beta, fz);
+                    __syncthreads(); __syncthreads();           // the two barriers inside a y / z tile
+                }
+                __syncthreads();                                 // the tiles' scan arrays are reused by the next round
+            }
+            NF_XS(0);
+            { const double sd = block_sum(dot, sred); if (tid == 0) ppq[widx] = sd; }
+            NF_XS(1);
+            if (!xcd_barrier(A.st, (unsigned)P * ++nbar, &s_i[3])) { err = 4; break; }
+            // lane i fetches workgroup i's partial (one L1-bypassing load for all of them; P dependent loads would be P trips to L2),
+            // then the fixed tree of wave_sum: every wavefront of every workgroup forms the same bits
+            NF_XS(2);
+            const double pq = wave_sum(lane < P ? __builtin_nontemporal_load(ppq + lane) : 0.0);     // src/solvers.cpp:602-606
+            NF_XS(3);
+            pend = 0;
+            if ((pq - pq) != 0.0) { err = 1; rr = pq; break; }
+            if (fabs(pq) < 1e-30) break;
+            alpha = rr / pq;
+            // ---- phase B: r -= alpha ((q_x + q_y) + q_z), |r|^2
+            // (all loads of an element go out before the first use: a load inside a predicated region is waited for there, one trip
+            // to L2 per operand instead of one per element; for dim < 3 the missing directions point at q_x and are not added)
+            double s = 0.0;
+            for (long i = (long)widx * XCD_THREADS + tid; i < N; i += (long)P * XCD_THREADS) {
+                const double q0 = __builtin_nontemporal_load(A.q[0] + i), q1 = __builtin_nontemporal_load(A.q[1] + i), q2 = __builtin_nontemporal_load(A.q[2] + i);
+                const double r0 = __builtin_nontemporal_load(A.r + i);
+                double q = q0;
+                if (dim >= 2) q += q1;
+                if (dim == 3) q += q2;
+                const double rn = r0 - alpha * q;
+                A.r[i] = rn; s += rn * rn;
+            }
+            { const double sd = block_sum(s, sred); if (tid == 0) prr[widx] = sd; }
+            NF_XS(4);
+            if (!xcd_barrier(A.st, (unsigned)P * ++nbar, &s_i[3])) { err = 4; break; }
+            NF_XS(5);
+            rr_new = wave_sum(lane < P ? __builtin_nontemporal_load(prr + lane) : 0.0);               // :613-631
+            if ((rr_new - rr_new) != 0.0) { err = 1; rr = rr_new; break; }
+            ++its; pend = 1;
+            NF_XS(6);
+            if (rr_new < tol_sq) { rr = rr_new; break; }
+            beta = rr_new / rr; rr = rr_new;
+            if (its >= maxit) break;
+        }
+#ifdef NF_XSTAMPS
+    if (widx == 0 && tid == 0) { for (int k = 0; k < 7; ++k) A.part[128 + k] += (double)xs[k]; A.part[135] += its; A.part[136] += 1; A.part[137] = P; A.part[138] = R; A.part[139] = wx * 10000 + wy * 100 + wz; }
+#endif
+    // ---- the last iteration's x_sol += alpha p (:609); its direction: see the buffer pair in cg_solve
+    if (pend && !err) {
+        const double *plast = (its >= 2 && ((its - 1) & 1)) ? A.pB : A.pA;
+        for (long i = (long)widx * XCD_THREADS + tid; i < N; i += (long)P * XCD_THREADS)
+            A.xsol[i] = fma(alpha, __builtin_nontemporal_load(plast + i), __builtin_nontemporal_load(A.xsol + i));
+    }
+    if (widx == 0 && tid == 0) {
+        CgScalars *cg = A.cg;
+        if (!cg->done || err) { cg->rr = rr; cg->rr_new = rr_new; cg->alpha = alpha; cg->beta = beta; cg->its = its; cg->pend = 0; cg->done = 1; cg->err = err; }
+        if (A.hp) { A.hp->cg = *cg; __threadfence_system(); __hip_atomic_store(&A.hp->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
-"""The three execution shapes of the full-Schur SolveKeff -- (0) host-driven outer loop with the classic four-launch CG,
-(0') the same with the fused-direction two-launch CG (k_apply3), (2) the resident one-workgroup kernel (k_resident_keff) --
+"""The execution shapes of the full-Schur SolveKeff -- (0) host-driven outer loop with the classic four-launch CG,
+(0') the same with the fused-direction two-launch CG (k_apply3), (0'') the same with every CG solve as one launch on the workgroups of
+one XCD (k_cg_xcd), (2) the resident one-workgroup kernel (k_resident_keff) --
 run the same per-cell arithmetic and differ only in the summation order of the dot products.  They must agree with each
 other and with the oracle: tightly at tight tolerances, and with the same iteration counts on well-conditioned problems."""
 import numpy as np
@@ -9,7 +10,11 @@ from helpers import TEST_TOL, degenerate_inputs, load_inputs, make_hip, make_ora
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
+PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=0), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
+         # whole CG solve in one launch on one XCD, forced onto every RT0-P0 mesh it can take; and the same aimed at an XCD that does not
+         # exist: nobody registers, the kernel reports it before touching a vector and the solver carries on through the launches
+         ("xcd", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=1, cg_xcd_min_cells=0, cg_xcd_max_cells=1 << 30), 0),
+         ("xcd-refused", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=1, cg_xcd_min_cells=0, cg_xcd_max_cells=1 << 30, cg_xcd_id=9), 0),
          ("resident-scans", dict(resident=1, resident_max_dofs=100000, resident_serial=0), 2),
          ("resident-one-sided", dict(resident=1, resident_max_dofs=100000, resident_two_sided=0), 2),   # one lane per line instead of a pair meeting in the middle
          ("classic-streaming", dict(resident=0, cg_fuse3=0, nt_min_cells=0), 0),   # the big-mesh instantiations (non-temporal loads) forced onto small meshes   # RT0-P0 small enough for LDS: "resident" is the line-per-lane variant
@@ -27,9 +32,21 @@ def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
     for k, v in opts.items():
         s.set_option(k, v)
     k, n = s.solve_keff(coarse, factors)
-    out = dict(k=k, n=n, cg=s.history()["cg"].copy(), hk=s.history()["k"].copy(), phi=s.get_phi().copy(), path=s.info("last_path"), J=s.get_J().copy())
+    out = dict(k=k, n=n, cg=s.history()["cg"].copy(), hk=s.history()["k"].copy(), phi=s.get_phi().copy(), path=s.info("last_path"), J=s.get_J().copy(),
+               xcd=s.info("xcd_solves"), refused=s.info("xcd_refused"))
     s.close()
     return out
+
+
+def _check_xcd(name, r, shape, p):
+    """k_cg_xcd ran where it can (P0 flux: one unknown per cell, RT0-P0 and RT1-P0; x lines of at most 128 cells) and only where it was asked to"""
+    can = p == 0 and shape[0] <= 128
+    if name == "xcd":
+        assert (r["xcd"] > 0) == can and r["refused"] == 0, (name, r["xcd"], r["refused"])
+    elif name == "xcd-refused":
+        assert r["xcd"] == 0 and r["refused"] == (1 if can else 0), (name, r["xcd"], r["refused"])
+    else:
+        assert r["xcd"] == 0 and r["refused"] == 0, (name, r["xcd"], r["refused"])
 
 
 @pytest.mark.parametrize("shape,rt,p,ng", [((24, 20, 6), 0, 0, 2), ((7, 6, 5), 0, 0, 3), ((19, 19, 1), 0, 0, 2), ((110, 1, 1), 1, 1, 2),
@@ -51,12 +68,14 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         if name == "resident-scans" and shape[0] > 128:
             path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
         assert r["path"] == path, (name, r["path"])
+        _check_xcd(name, r, shape, p)
         assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
         assert rel_l2(r["J"].ravel(), o.J_dofs().ravel()) < 1e-7, name
     assert res["classic-streaming"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-streaming"]["phi"], res["classic"]["phi"])   # same arithmetic, other load instructions
     assert res["classic-no-host-page"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-no-host-page"]["phi"], res["classic"]["phi"])   # readback route only
-    for name in ("fuse3", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
+    assert res["xcd-refused"]["k"] == res["fuse3"]["k"] and np.array_equal(res["xcd-refused"]["phi"], res["fuse3"]["phi"])   # the fall-back IS the launch path
+    for name in ("fuse3", "xcd", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
         if name not in res:
             continue
         assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
@@ -79,6 +98,7 @@ def test_paths_fixed_work_histories(shape, rt, ng):
             continue
         r = _run(inp, rt, rt, tol, opts)
         assert r["path"] == path and r["n"] == 6, (name, r["path"], r["n"])
+        _check_xcd(name, r, shape, rt)
         np.testing.assert_allclose(r["hk"], ho["k"], rtol=1e-9, err_msg=name)
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
 
