@@ -164,11 +164,11 @@ struct nf_team {
     int opt_fuse3 = 1; long fuse3_max_cells = 400000;
     // whole CG solve in one launch on the workgroups of one XCD (k_cg_xcd): RT0-P0 meshes between the one-workgroup resident kernel and
     // xcd_max_cells.  One XCD has an eighth of the chip's compute units and L2 (4 MiB): beyond that the launch path wins back.
-    int opt_cgx = 1, xcd_id = 0, xcd_groups = 32, last_xcd = 0; long xcd_min_cells = 2000, xcd_max_cells = 28000, xcd_solves = 0, xcd_refused = 0;
+    int opt_cgx = 1, opt_keffx = 1, xcd_id = 0, xcd_groups = 32, last_xcd = 0; long xcd_min_cells = 2000, xcd_max_cells = 28000, xcd_solves = 0, xcd_refused = 0;
     XcdState *d_xcd = nullptr; double *d_xpart = nullptr;
     int opt_resident = 1, opt_resident_lds = 1, opt_resident_serial = 1, opt_resident_two_sided = 1, last_resident_serial = 0; long resident_max_dofs = 2500, resident_serial_max_dofs = 5120;  // whole SolveKeff in one workgroup (k_resident_keff) up to this many flux DOFs per group
     int *d_hist_cg = nullptr; int hist_cg_cap = 0; ResidentOut *d_rout = nullptr;
-    int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel (nf_info "last_path")
+    int last_path = 0;                                    // 0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel, 3 one-XCD kernel (nf_info "last_path")
     long direct_max_dofs = 6000;                          // explicit-S branch with a dense S^-1 up to this many flux DOFs per group (the oracle's own limit: exact on both sides over the same range; 288 MB per group at 6000)
     int last_direct = 0;                                  // the last solve used: 0 CG as configured, 1 dense S^-1, 2 CG to 1e-14 standing in
     long standin_unconverged = 0;                         // group solves of the stand-in that ended above 1e-14
@@ -1412,13 +1412,14 @@ static bool xcd_eligible(const nf_team *T, const nf_solver *S, const Fuse3Plan &
     for (int r = 0; r < 2; ++r) if (S->dim >= r + 2 && (P.A.NSEG[r] >= 64 || P.A.TX[r] * P.A.NSEG[r] > 448)) return false;   // no wavefront scan in the packed tiles; a tile fits beside the other roles
     return S->nx <= 128;                                          // x lines: at most two chunks per lane (128 VGPRs at 1024 threads)
 }
-static int launch_cg_xcd(nf_solver *S, int g, const Fuse3Plan &P, double *xsol, unsigned long long seq)
+// geometry, factors (of group g) and CG vectors of a k_cg_xcd / k_keff_xcd launch; *nch_out: chunks per lane of the x lines
+static int xcd_fill(nf_solver *S, int g, const Fuse3Plan &P, XcdArgs &A, int *nch_out)
 {
-    nf_team *T = S->team; hipStream_t st = T->stream;
+    nf_team *T = S->team;
     const long N = S->N;
-    if (!T->d_xcd) { HIPCHK(hipMalloc((void **)&T->d_xcd, sizeof(XcdState))); NFCHK(dalloc(&T->d_xpart, 256)); HIPCHK(hipMemset(T->d_xpart, 0, 256 * sizeof(double))); }
-    HIPCHK(hipMemsetAsync(T->d_xcd, 0, sizeof(XcdState), st));
-    XcdArgs A; memset(&A, 0, sizeof A);
+    if (!T->d_xcd) { HIPCHK(hipMalloc((void **)&T->d_xcd, sizeof(XcdState))); NFCHK(dalloc(&T->d_xpart, 512)); HIPCHK(hipMemset(T->d_xpart, 0, 512 * sizeof(double))); }
+    HIPCHK(hipMemsetAsync(T->d_xcd, 0, sizeof(XcdState), T->stream));
+    memset(&A, 0, sizeof A);
     A.G = make_geom(S);
     double *qd[3] = { S->d_q, S->d_qy, S->d_qz };
     for (int d = 0; d < 3; ++d) {
@@ -1427,7 +1428,7 @@ static int launch_cg_xcd(nf_solver *S, int g, const Fuse3Plan &P, double *xsol, 
         A.L[d] = S->d_L[dd] + g * N; A.DR[d] = S->d_DR[dd] + g * N; A.D0[d] = S->d_D0[dd] + g * S->nlines[dd]; A.q[d] = qd[dd];
     }
     A.nx = S->nx; A.ny = S->ny; A.dim = S->dim; A.nlines_x = S->nlines[0]; A.N = S->nphi;
-    // x lines: few wavefronts matter more here than short scans (the roles share the 16 wavefronts of a workgroup, and a second round
+    // x lines: few wavefronts matter more here than short scans (the roles share the 12 wavefronts of a workgroup, and a second round
     // costs a whole memory round trip): two chunks per lane from 33 cells on -- 38 cells = 16 lanes x 2 cells x 2 chunks, four lines
     // per wavefront, where the launch path takes 32 lanes and two lines
     int lanes = (S->nx + 1) / 2, lpl_log2 = 0;
@@ -1444,9 +1445,19 @@ static int launch_cg_xcd(nf_solver *S, int g, const Fuse3Plan &P, double *xsol, 
     A.lpl_log2 = lpl_log2; A.ntask_x = (int)((S->nlines[0] + (64 >> lpl_log2) - 1) / (64 >> lpl_log2));
     for (int r = 0; r < 2; ++r) { A.n[r] = P.A.n[r]; A.TX[r] = P.A.TX[r]; A.NSEG[r] = P.A.NSEG[r]; A.gx[r] = P.A.gx[r]; A.gy[r] = P.A.gy[r]; A.sl[r] = P.A.sl[r]; A.ostride[r] = P.A.ostride[r]; }
     if (S->dim < 2) { A.TX[0] = A.NSEG[0] = 1; } if (S->dim < 3) { A.TX[1] = A.NSEG[1] = 1; }
-    A.pA = S->d_p; A.pB = S->d_p2; A.r = S->d_r; A.xsol = xsol;
-    A.cg = T->d_cg; A.part = T->d_xpart; A.st = T->d_xcd; A.hp = T->d_pub; A.seq = seq; A.xcc = T->xcd_id;
-    const size_t lds = (size_t)(5 * 1024 + 64 + 32) * sizeof(double);
+    A.pA = S->d_p; A.pB = S->d_p2; A.r = S->d_r;
+    A.part = T->d_xpart; A.st = T->d_xcd; A.xcc = T->xcd_id;
+    *nch_out = nch;
+    return NF_OK;
+}
+static const size_t XCD_LDS = (size_t)(5 * 1024 + 64 + 32) * sizeof(double);
+static int launch_cg_xcd(nf_solver *S, int g, const Fuse3Plan &P, double *xsol, unsigned long long seq)
+{
+    nf_team *T = S->team; hipStream_t st = T->stream;
+    XcdArgs A; int nch = 1;
+    NFCHK(xcd_fill(S, g, P, A, &nch));
+    A.xsol = xsol; A.cg = T->d_cg; A.hp = T->d_pub; A.seq = seq;
+    const size_t lds = XCD_LDS;
     const unsigned G = 8u * (unsigned)T->xcd_groups;
 #define NF_XCD(NCHV, VECV) do { if (!lds_opt_in((const void *)k_cg_xcd<NCHV, VECV>, lds)) return fail(NF_ERR_HIP, "k_cg_xcd: %zu bytes of LDS refused", lds); \
         hipLaunchKernelGGL((k_cg_xcd<NCHV, VECV>), dim3(G), dim3(XCD_THREADS), lds, st, A); } while (0)
@@ -2027,7 +2038,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
         CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
-        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_cgx = T->opt_cgx; CT->xcd_min_cells = T->xcd_min_cells; CT->xcd_max_cells = T->xcd_max_cells; CT->xcd_id = T->xcd_id; CT->xcd_groups = T->xcd_groups; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
+        CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_cgx = T->opt_cgx; CT->opt_keffx = T->opt_keffx; CT->xcd_min_cells = T->xcd_min_cells; CT->xcd_max_cells = T->xcd_max_cells; CT->xcd_id = T->xcd_id; CT->xcd_groups = T->xcd_groups; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
     double kc = 1.0; int nout = 0;
@@ -2561,6 +2572,58 @@ static int solve_keff_resident(nf_team *T, const nf_keff_opts *o, double keff0, 
     return NF_OK;
 }
 
+// ---- whole SolveKeff on one XCD (k_keff_xcd): the meshes of k_cg_xcd, iterative full-Schur path ------------------------
+// returns NF_RESIDENT_UNAVAILABLE when the workgroups did not assemble (nothing has been touched: the host-driven path takes over)
+static int solve_keff_xcd(nf_team *T, const nf_keff_opts *o, const Fuse3Plan &P, double keff0, const double *ca, const double *cbv, double sigma,
+                          double cg_tol, int cg_max, double *keff_out)
+{
+    nf_solver *S = T->slabs[0];
+    const int ng = S->ng; hipStream_t st = T->stream;
+    if (!S->d_p2) NFCHK(dalloc(&S->d_p2, S->nphi));
+    if (S->dim >= 2 && !S->d_qy) NFCHK(dalloc(&S->d_qy, S->nphi));
+    if (S->dim == 3 && !S->d_qz) NFCHK(dalloc(&S->d_qz, S->nphi));
+    XcdArgs A; int nch = 1;
+    NFCHK(xcd_fill(S, 0, P, A, &nch));
+    XcdOuter O; memset(&O, 0, sizeof O);
+    O.ng = ng; O.NP = S->nphi; O.N = S->N;
+    O.Mf = S->d_Mf; O.Chi = S->d_Chi; O.Ms = S->d_Ms_tab;
+    O.phi = S->d_phi; O.raw = S->d_raw; O.p0 = S->d_p0; O.p1 = S->d_p1; O.tf = S->d_tf;
+    for (int d = 0; d < 3; ++d) O.nl[d] = S->nlines[d < S->dim ? d : 0];
+    O.keff0 = keff0; O.tol_keff = o->tol_keff; O.tol_flux = o->tol_flux; O.cg_tol = cg_tol; O.cg_max = cg_max; O.max_outer = o->max_outer;
+    O.ca1 = ca[1];
+    for (int i = 2; i < 15; ++i) { O.a3[i] = (4. / sigma) * ca[i]; O.cb[i] = cbv[i]; }
+    if (T->hist_cap < o->max_outer) { NFCHK(dalloc(&T->d_hist, (size_t)3 * o->max_outer + 8)); T->hist_cap = o->max_outer; }
+    if (T->hist_cg_cap < o->max_outer * ng) { NFCHK(dalloc(&T->d_hist_cg, (size_t)o->max_outer * ng)); T->hist_cg_cap = o->max_outer * ng; }
+    if (!T->d_rout) NFCHK(dalloc(&T->d_rout, 1));
+    O.hist = T->d_hist; O.hist_cg = T->d_hist_cg; O.out = T->d_rout;
+    const size_t lds = XCD_LDS;
+    const unsigned G = 8u * (unsigned)T->xcd_groups;
+#define NF_XK(NCHV, VECV) do { if (!lds_opt_in((const void *)k_keff_xcd<NCHV, VECV>, lds)) return NF_RESIDENT_UNAVAILABLE; \
+        hipLaunchKernelGGL((k_keff_xcd<NCHV, VECV>), dim3(G), dim3(XCD_THREADS), lds, st, A, O); } while (0)
+    if (nch == 1) { if (P.vec) NF_XK(1, true); else NF_XK(1, false); }
+    else { if (P.vec) NF_XK(2, true); else NF_XK(2, false); }
+#undef NF_XK
+    HIPCHK(hipGetLastError());
+    ResidentOut ro;
+    HIPCHK(hipMemcpyAsync(&ro, T->d_rout, sizeof ro, hipMemcpyDeviceToHost, st));
+    HIPCHK(stream_wait(st));
+    if (ro.status == 3) { T->opt_keffx = 0; T->opt_cgx = 0; ++T->xcd_refused; return NF_RESIDENT_UNAVAILABLE; }
+    if (ro.status == 4) { T->opt_keffx = 0; T->opt_cgx = 0; return fail(NF_ERR_HIP, "XCD-local SolveKeff (k_keff_xcd): a grid barrier timed out in outer iteration %d (a participant was lost); the path is now off for this solver", ro.n_outer); }
+    const int n = ro.n_outer;
+    T->hist_k.resize(n); T->hist_dk.resize(n); T->hist_dphi.resize(n); T->hist_cg.resize((size_t)n * ng);
+    if (n > 0) {
+        HIPCHK(hipMemcpy(T->hist_k.data(), T->d_hist, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_dk.data(), T->d_hist + o->max_outer, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_dphi.data(), T->d_hist + 2 * (size_t)o->max_outer, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T->hist_cg.data(), T->d_hist_cg, (size_t)n * ng * sizeof(int), hipMemcpyDeviceToHost));
+        for (int g = 0; g < ng; ++g) T->last_its[g] = T->hist_cg[(size_t)(n - 1) * ng + g];
+    }
+    T->last_outer = n; T->last_cg_total = ro.cg_total; T->xcd_solves += (long)n * ng; T->last_xcd = 1;
+    if (ro.status == 2) return fail(NF_ERR_NUMERIC, "power iteration diverged (outer %d: k=%g dphi=%g)", n - 1, n > 0 ? T->hist_k[n - 1] : 0.0, n > 0 ? T->hist_dphi[n - 1] : 0.0);
+    *keff_out = ro.keff;
+    return NF_OK;
+}
+
 // ---- SolveKeff (src/NeutFEM.cpp:1627-1815) -----------------------------------------------------
 static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, int *n_outer)
 {
@@ -2627,6 +2690,24 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
                 return NF_OK;
             }
             T->last_path = 0; T->profile = prof_req;              // the device refused the LDS the resident kernel plans with: host-driven path
+        }
+    }
+    // mid-size meshes with one unknown per cell: the whole power iteration in one launch on one XCD (k_keff_xcd)
+    if (single && !use_diag && !use_cmfd && !direct && !dense && !T->rccl_reduce && o->max_outer > 0 && T->opt_keffx && T->opt_fuse && T->opt_lean && T->opt_fuse3 &&
+        S0->N <= T->fuse3_max_cells && S0->N <= T->lean_max_cells) {
+        const Fuse3Plan f3 = fuse3_plan(S0);
+        if (xcd_eligible(T, S0, f3)) {
+            T->last_path = 3;
+            const int rx = solve_keff_xcd(T, o, f3, keff, ca, cbv, sigma, cg_tol, cg_max, &keff);
+            if (rx != NF_RESIDENT_UNAVAILABLE) {
+                NFCHK(rx);
+                S0->raw_valid = T->last_outer > 0; S0->raw_is_diag = false; S0->jz_valid = false;
+                T->has_valid_keff = 1; T->last_keff = keff;
+                if (keff_out) *keff_out = keff;
+                if (n_outer) *n_outer = T->last_outer;
+                return NF_OK;
+            }
+            T->last_path = 0;
         }
     }
     ScatterArgs sa; sa.ng = ng;
@@ -3071,6 +3152,7 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "direct_max_dofs")) T->direct_max_dofs = std::max(0L, std::min(8192L, value));
     else if (!strcmp(key, "cg_fuse3")) T->opt_fuse3 = value != 0;
     else if (!strcmp(key, "cg_xcd")) T->opt_cgx = value != 0;
+    else if (!strcmp(key, "keff_xcd")) T->opt_keffx = value != 0;
     else if (!strcmp(key, "cg_xcd_min_cells")) T->xcd_min_cells = value;
     else if (!strcmp(key, "cg_xcd_max_cells")) T->xcd_max_cells = value;
     else if (!strcmp(key, "cg_xcd_id")) T->xcd_id = (int)(value & 15);   // 8..15: no such XCD -- nobody registers, the solve falls back (tests)

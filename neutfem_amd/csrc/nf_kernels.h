@@ -1527,6 +1527,7 @@ __global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, con
 // TX NSEG threads packed into the role's waves; the x waves keep the two barriers of a tile company).
 // Partial sums: one per workgroup, added in workgroup order -- not the order of the launch path, so the iterates differ from it in
 // the last bits (like the resident kernel's do); every run gives the same bits.
+struct ResidentOut { double keff; int n_outer, status, cg_total, pad; };   // status 0 ok, 2 diverged (non-finite k or dphi); k_keff_xcd: 3 not assembled, 4 barrier timeout
 struct XcdState { unsigned arrived, nreg, count, timeout; };
 struct XcdArgs {
     ModeArgs ma[3]; Geom G;
@@ -1535,7 +1536,7 @@ struct XcdArgs {
     int ntask_x, lpl_log2;
     int n[2], TX[2], NSEG[2], gx[2], gy[2]; long sl[2], ostride[2];   // y (0) and z (1) tiles
     double *pA, *pB, *r, *xsol; const double *q[3];
-    CgScalars *cg; double *part;                                      // part: 2 x 64 doubles (p.q | |r|^2 partials)
+    CgScalars *cg; double *part;                                      // part: 4 rotating slots of 64 partials (xcd_total), then p.q | |r|^2 partials of the CG, then diagnostics: 512 doubles
     XcdState *st; HostPub *hp; unsigned long long seq; int xcc;
 };
 __device__ __forceinline__ unsigned xld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1562,32 +1563,36 @@ __device__ __forceinline__ bool xcd_barrier(XcdState *st, unsigned target, int *
     return *s_ok != 0;
 }
 constexpr int XCD_THREADS = 768;                                 // 12 wavefronts = 3 per SIMD: 170 VGPRs (at 1024 threads the 128-VGPR budget spilled into the loop: a reload from scratch is a trip to L2 there)
-template <int NCH, bool VEC>
-__global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
+// what a workgroup knows once the participants have assembled: its index, their number, and how its wavefronts split among the roles
+struct XcdCtx {
+    int widx, P; bool ok;
+    int R, wx, dx, role;                                          // rounds of phase A; x role: wavefronts per round, wave-tasks of this workgroup
+    int sT, sC, sPer, sNt, sTX, sNSEG, sGx, sGy, sN, sSlot, sLtid; long sSl, sOst; bool isz; double *sSm;   // tile waves: their direction's parameters
+    unsigned nbar; int nred;                                      // barriers passed; reductions made (partial slots rotate)
+};
+// registration: returns false for a workgroup that leaves (not on the chosen XCD).  *none: this workgroup was the last of the grid to
+// start and nobody registered -- it must tell the host.
+__device__ __forceinline__ bool xcd_assemble(XcdState *st, int xcc, int *s_i, XcdCtx &C, bool *none)
 {
-    extern __shared__ double sm[];
-    __shared__ int s_i[4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *const sred = sm + 5 * 1024 + 64;
     unsigned id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-    const bool part = (int)(id & 0xf) == A.xcc;
-    if (tid == 0) {
-        s_i[0] = part ? (int)__hip_atomic_fetch_add(&A.st->nreg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        const unsigned before = __hip_atomic_fetch_add(&A.st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (before + 1 == gridDim.x && xld(&A.st->nreg) == 0) {  // the last workgroup to start, and nobody sits on the chosen XCD: say so
-            A.cg->err = 3; A.cg->done = 1;
-            if (A.hp) { A.hp->cg = *A.cg; __threadfence_system(); __hip_atomic_store(&A.hp->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-        }
+    const bool part = (int)(id & 0xf) == xcc;
+    *none = false;
+    if (threadIdx.x == 0) {
+        s_i[0] = part ? (int)__hip_atomic_fetch_add(&st->nreg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        const unsigned before = __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *none = before + 1 == gridDim.x && xld(&st->nreg) == 0;
     }
-    if (!part) return;
-    if (tid == 0) { s_i[2] = xcd_spin(&A.st->arrived, gridDim.x, &A.st->timeout) ? 1 : 0; s_i[1] = (int)xld(&A.st->nreg); }
+    if (!part) return false;
+    if (threadIdx.x == 0) { s_i[2] = xcd_spin(&st->arrived, gridDim.x, &st->timeout) ? 1 : 0; s_i[1] = (int)xld(&st->nreg); }
     __syncthreads();
-    const int widx = s_i[0], P = s_i[1];
-    bool ok = s_i[2] != 0 && P <= 64;
-    const int dim = A.dim; const long N = A.N;
-    // ---- this workgroup's share and the split of its wavefronts among the roles (see the header)
+    C.widx = s_i[0]; C.P = s_i[1]; C.ok = s_i[2] != 0 && C.P <= 64;
+    C.nbar = 0; C.nred = 0;
+    return true;
+}
+__device__ __forceinline__ void xcd_plan(const XcdArgs &A, XcdCtx &C, int tid, int wave, double *sm)
+{
+    const int P = C.P, dim = A.dim;
     const int Ty = A.TX[0] * A.NSEG[0], Tz = A.TX[1] * A.NSEG[1];
     const int nty = dim >= 2 ? A.gx[0] * A.gy[0] : 0, ntz = dim == 3 ? A.gx[1] * A.gy[1] : 0;
     const int dx = (A.ntask_x + P - 1) / P, ty = (nty + P - 1) / P, tz = (ntz + P - 1) / P;
@@ -1597,52 +1602,84 @@ __global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
         wy = (cy * Ty + 63) >> 6; wz = (cz * Tz + 63) >> 6;
         if (wx + wy + wz <= XCD_THREADS / 64 || R >= 4096) break;
     }
-    if (wx + wy + wz > XCD_THREADS / 64) ok = false;
-    const int role = wave < wx ? 0 : wave < wx + wy ? 1 : wave < wx + wy + wz ? 2 : 3;
-    // y and z tiles run the same code (RT0-P0: the direction is nothing but strides): a tile wave picks its direction's parameters once
-    const bool isz = role == 2;
-    const int sT = isz ? Tz : Ty, sC = isz ? cz : cy, sPer = isz ? tz : ty, sNt = isz ? ntz : nty;
-    const int sTX = isz ? A.TX[1] : A.TX[0], sNSEG = isz ? A.NSEG[1] : A.NSEG[0], sGx = isz ? A.gx[1] : A.gx[0], sGy = isz ? A.gy[1] : A.gy[0], sN = isz ? A.n[1] : A.n[0];
-    const long sSl = isz ? A.sl[1] : A.sl[0], sOst = isz ? A.ostride[1] : A.ostride[0];
-    const double *const sL = isz ? A.L[2] : A.L[1], *const sDR = isz ? A.DR[2] : A.DR[1], *const sD0 = isz ? A.D0[2] : A.D0[1];
-    ModeArgs ms = A.ma[0]; ms.Ta = isz ? A.ma[2].Ta : A.ma[1].Ta; ms.y[0] = isz ? A.ma[2].y[0] : A.ma[1].y[0];
-    const int sLt = tid - (isz ? wx + wy : wx) * 64, sSlot = sLt / sT, sLtid = sLt - sSlot * sT;
-    double *const sSm = sm + (isz ? cy * (4 * Ty + A.TX[0]) : 0) + ((sSlot >= 0 && sSlot < sC) ? sSlot : 0) * (4 * sT + sTX);
-    ModeArgs mx = A.ma[0];
+    if (wx + wy + wz > XCD_THREADS / 64) C.ok = false;
+    C.R = R; C.wx = wx; C.dx = dx;
+    C.role = wave < wx ? 0 : wave < wx + wy ? 1 : wave < wx + wy + wz ? 2 : 3;
+    // y and z tiles run the same code (one unknown per cell: the direction is nothing but strides): a tile wave picks its direction's parameters once
+    const bool isz = C.role == 2;
+    C.isz = isz;
+    C.sT = isz ? Tz : Ty; C.sC = isz ? cz : cy; C.sPer = isz ? tz : ty; C.sNt = isz ? ntz : nty;
+    C.sTX = isz ? A.TX[1] : A.TX[0]; C.sNSEG = isz ? A.NSEG[1] : A.NSEG[0]; C.sGx = isz ? A.gx[1] : A.gx[0]; C.sGy = isz ? A.gy[1] : A.gy[0]; C.sN = isz ? A.n[1] : A.n[0];
+    C.sSl = isz ? A.sl[1] : A.sl[0]; C.sOst = isz ? A.ostride[1] : A.ostride[0];
+    const int sLt = tid - (isz ? wx + wy : wx) * 64;
+    C.sSlot = sLt / C.sT; C.sLtid = sLt - C.sSlot * C.sT;
+    C.sSm = sm + (isz ? cy * (4 * Ty + A.TX[0]) : 0) + ((C.sSlot >= 0 && C.sSlot < C.sC) ? C.sSlot : 0) * (4 * C.sT + C.sTX);
+}
+// grid-wide sum, the same bits in every thread of every participant: one partial per workgroup (block_sum), barrier, lane i fetches
+// workgroup i's partial with one L1-bypassing load (P dependent loads would be P trips to L2), then wave_sum's fixed tree.  The partial
+// slots rotate (four of them), so a slot is rewritten three barriers after its readers have moved on.  NV values share one barrier.
+template <int NV>
+__device__ __forceinline__ bool xcd_total(double (&v)[NV], double *part, XcdState *st, XcdCtx &C, double *sred, int *s_ok)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    double *slot[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        slot[k] = part + 64 * (C.nred++ & 3);
+        const double sd = block_sum(v[k], sred);
+        if (tid == 0) slot[k][C.widx] = sd;
+        if (k + 1 < NV) __syncthreads();
+    }
+    if (!xcd_barrier(st, (unsigned)C.P * ++C.nbar, s_ok)) return false;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(lane < C.P ? __builtin_nontemporal_load(slot[k] + lane) : 0.0);
+    return true;
+}
+// The CG solve of one group (src/solvers.cpp:577-636) by the assembled workgroups: x_sol = 0, r = p = rhs in pA and |rhs|^2 = rr are
+// in place.  offN / offP / offL*: this group's offsets into the factor arrays (cells), the C diagonal (unknowns) and the first pivots (lines).
+// err: 0, 1 (non-finite sum), 4 (a barrier timed out).  On return x_sol holds the solution (the deferred last update applied).
+template <int NCH, bool VEC>
+__device__ __forceinline__ void xcd_cg(const XcdArgs &A, XcdCtx &C, long offN, long offP, long offL0, long offL1, long offL2, double *xsol,
+                                       double &rr, double tol_sq, int maxit, int &its, int &err, double *sred, int *s_ok, long long *xs)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dim = A.dim; const long N = A.N; const int P = C.P, widx = C.widx;
     SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = sa0.noacc = 0; sa0.yadd = nullptr; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
-    // ---- scalars as k_finalize(FIN_RHS) left them (a launch earlier)
-    double rr = A.cg->rr, alpha = 0.0, beta = 0.0, rr_new = A.cg->rr;
-    const double tol_sq = A.cg->tol_sq; const int maxit = A.cg->maxit;
-    int its = 0, pend = 0, err = ok ? 0 : 3;
-    unsigned nbar = 0;
-    double *const ppq = A.part, *const prr = A.part + 64;
+    const double *const sL = (C.isz ? A.L[2] : A.L[1]) + offN, *const sDR = (C.isz ? A.DR[2] : A.DR[1]) + offN, *const sD0 = C.isz ? A.D0[2] + offL2 : A.D0[1] + offL1;
+    ModeArgs ms = A.ma[0]; ms.Ta = C.isz ? A.ma[2].Ta : A.ma[1].Ta; ms.y[0] = C.isz ? A.ma[2].y[0] : A.ma[1].y[0];
+    ModeArgs mx = A.ma[0]; mx.Cd[0] = A.ma[0].Cd[0] + offP;
+    double alpha = 0.0, beta = 0.0, rr_new = rr;
+    int pend = 0;
+    double *const ppq = A.part + 256, *const prr = A.part + 320;
 #ifdef NF_XSTAMPS
-    long long xs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, xt = (long long)__builtin_amdgcn_s_memrealtime();
+    long long xt = (long long)__builtin_amdgcn_s_memrealtime();
 #define NF_XS(k) do { const long long t_ = (long long)__builtin_amdgcn_s_memrealtime(); xs[k] += t_ - xt; xt = t_; } while (0)
 #else
+    (void)xs;
 #define NF_XS(k) do { } while (0)
 #endif
-    if (ok && !A.cg->done)
+    its = 0; err = 0;
+    if (maxit > 0)
         for (;;) {
             const bool fuse = its > 0;
             double *const pin = (its == 0 || (its & 1)) ? A.pA : A.pB, *const pout = pin == A.pA ? A.pB : A.pA;
-            const CgFuse fz = { pin, A.r, A.xsol, pout };
+            const CgFuse fz = { pin, A.r, xsol, pout };
             // ---- phase A: q_d = S_d p for every direction, p.q
             double dot = 0.0;
-            for (int ro = 0; ro < R; ++ro) {
-                if (role == 1 || role == 2) {
-                    const int k = ro * sC + sSlot, t = widx * sPer + k;
-                    const bool act = sSlot < sC && k < sPer && t < sNt;
+            for (int ro = 0; ro < C.R; ++ro) {
+                if (C.role == 1 || C.role == 2) {
+                    const int k = ro * C.sC + C.sSlot, t = widx * C.sPer + k;
+                    const bool act = C.sSlot < C.sC && k < C.sPer && t < C.sNt;
                     const unsigned tt = act ? t : 0;
                     ms.x[0] = pin;
-                    dot += schur_s_tile<8, 1, false, 0, true, false, NoMid, false, true>(ms, A.G, sL, sDR, sD0, sN, sSl, sOst, A.nx, sTX, sNSEG, tt % sGx, tt / sGx, 0, sGy,
-                                                                                          sLtid, act, sSm, sa0, fz, false, fuse, alpha, beta, false);
+                    dot += schur_s_tile<8, 1, false, 0, true, false, NoMid, false, true>(ms, A.G, sL, sDR, sD0, C.sN, C.sSl, C.sOst, A.nx, C.sTX, C.sNSEG, tt % C.sGx, tt / C.sGx, 0, C.sGy,
+                                                                                          C.sLtid, act, C.sSm, sa0, fz, false, fuse, alpha, beta, false);
                 } else {
-                    const int k = ro * wx + wave; const long gt = (long)widx * dx + k;
-                    const bool act = role == 0 && k < dx && gt < A.ntask_x;
+                    const int k = ro * C.wx + wave; const long gt = (long)widx * C.dx + k;
+                    const bool act = C.role == 0 && k < C.dx && gt < A.ntask_x;
                     mx.x[0] = pin;
-                    dot += schur_x_task<2, NCH, VEC, 0, NoMid, true, true>(mx, A.G, A.L[0], A.DR[0], A.D0[0], A.nx, A.ny, A.nlines_x, A.lpl_log2, 1, act ? gt : 0, lane, act,
-                                                                           fuse, alpha, beta, fz);
+                    dot += schur_x_task<2, NCH, VEC, 0, NoMid, true, true>(mx, A.G, A.L[0] + offN, A.DR[0] + offN, A.D0[0] + offL0, A.nx, A.ny, A.nlines_x, A.lpl_log2, 1, act ? gt : 0, lane, act,
+                                                                          fuse, alpha, beta, fz);
                     __syncthreads(); __syncthreads();           // the two barriers inside a y / z tile
                 }
                 __syncthreads();                                 // the tiles' scan arrays are reused by the next round
@@ -1650,9 +1687,7 @@ __global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
             NF_XS(0);
             { const double sd = block_sum(dot, sred); if (tid == 0) ppq[widx] = sd; }
             NF_XS(1);
-            if (!xcd_barrier(A.st, (unsigned)P * ++nbar, &s_i[3])) { err = 4; break; }
-            // lane i fetches workgroup i's partial (one L1-bypassing load for all of them; P dependent loads would be P trips to L2),
-            // then the fixed tree of wave_sum: every wavefront of every workgroup forms the same bits
+            if (!xcd_barrier(A.st, (unsigned)P * ++C.nbar, s_ok)) { err = 4; break; }
             NF_XS(2);
             const double pq = wave_sum(lane < P ? __builtin_nontemporal_load(ppq + lane) : 0.0);     // src/solvers.cpp:602-606
             NF_XS(3);
@@ -1675,7 +1710,7 @@ __global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
             }
             { const double sd = block_sum(s, sred); if (tid == 0) prr[widx] = sd; }
             NF_XS(4);
-            if (!xcd_barrier(A.st, (unsigned)P * ++nbar, &s_i[3])) { err = 4; break; }
+            if (!xcd_barrier(A.st, (unsigned)P * ++C.nbar, s_ok)) { err = 4; break; }
             NF_XS(5);
             rr_new = wave_sum(lane < P ? __builtin_nontemporal_load(prr + lane) : 0.0);               // :613-631
             if ((rr_new - rr_new) != 0.0) { err = 1; rr = rr_new; break; }
@@ -1685,20 +1720,153 @@ __global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
             beta = rr_new / rr; rr = rr_new;
             if (its >= maxit) break;
         }
-#ifdef NF_XSTAMPS
-    if (widx == 0 && tid == 0) { for (int k = 0; k < 7; ++k) A.part[128 + k] += (double)xs[k]; A.part[135] += its; A.part[136] += 1; A.part[137] = P; A.part[138] = R; A.part[139] = wx * 10000 + wy * 100 + wz; }
-#endif
     // ---- the last iteration's x_sol += alpha p (:609); its direction: see the buffer pair in cg_solve
     if (pend && !err) {
         const double *plast = (its >= 2 && ((its - 1) & 1)) ? A.pB : A.pA;
         for (long i = (long)widx * XCD_THREADS + tid; i < N; i += (long)P * XCD_THREADS)
-            A.xsol[i] = fma(alpha, __builtin_nontemporal_load(plast + i), __builtin_nontemporal_load(A.xsol + i));
+            xsol[i] = fma(alpha, __builtin_nontemporal_load(plast + i), __builtin_nontemporal_load(xsol + i));
     }
-    if (widx == 0 && tid == 0) {
+}
+template <int NCH, bool VEC>
+__global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
+{
+    extern __shared__ double sm[];
+    __shared__ int s_i[4];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *const sred = sm + 5 * 1024 + 64;
+    XcdCtx C; bool none;
+    const bool part = xcd_assemble(A.st, A.xcc, s_i, C, &none);
+    if (none) {                                                   // nobody sits on the chosen XCD: say so
+        A.cg->err = 3; A.cg->done = 1;
+        if (A.hp) { A.hp->cg = *A.cg; __threadfence_system(); __hip_atomic_store(&A.hp->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
+    if (!part) return;
+    xcd_plan(A, C, tid, wave, sm);
+    // ---- scalars as k_finalize(FIN_RHS) left them (a launch earlier)
+    double rr = A.cg->rr;
+    const double tol_sq = A.cg->tol_sq; const int maxit = A.cg->maxit;
+    int its = 0, err = C.ok ? 0 : 3;
+    long long xs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (C.ok && !A.cg->done) xcd_cg<NCH, VEC>(A, C, 0, 0, 0, 0, 0, A.xsol, rr, tol_sq, maxit, its, err, sred, &s_i[3], xs);
+#ifdef NF_XSTAMPS
+    if (C.widx == 0 && tid == 0) { for (int k = 0; k < 7; ++k) A.part[384 + k] += (double)xs[k]; A.part[391] += its; A.part[392] += 1; A.part[393] = C.P; A.part[394] = C.R; A.part[395] = C.wx; }
+#endif
+    if (C.widx == 0 && tid == 0) {
         CgScalars *cg = A.cg;
-        if (!cg->done || err) { cg->rr = rr; cg->rr_new = rr_new; cg->alpha = alpha; cg->beta = beta; cg->its = its; cg->pend = 0; cg->done = 1; cg->err = err; }
+        if (!cg->done || err) { cg->rr = rr; cg->rr_new = rr; cg->its = its; cg->pend = 0; cg->done = 1; cg->err = err; }
         if (A.hp) { A.hp->cg = *cg; __threadfence_system(); __hip_atomic_store(&A.hp->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
+}
+
+// The whole SolveKeff (src/NeutFEM.cpp:1627-1815: fission source, Gauss-Seidel group sweep with CG, k update, normalisation, Chebyshev,
+// stop tests, history) of the same meshes in ONE launch on the workgroups of one XCD: what k_resident_keff does in one workgroup for
+// meshes that fit its LDS, with grid barriers in the place of workgroup barriers.  Beside the CG iterations themselves this removes
+// what surrounds them on the host-driven path: per group solve five stream operations and a host check, per outer iteration four
+// launches and a host check (IAEA-3D 38x38x19: ~6 ms of 22).  Elementwise loops are grid-strided; every vector is read with
+// L1-bypassing loads, and a barrier separates every phase that writes a vector from the phases that read it under another ownership.
+// Every workgroup carries the scalars (k, Chebyshev state, stop tests) itself, from the same sums: uniform control flow, no flags.
+struct XcdOuter {
+    int ng; long NP, N;
+    const double *Mf, *Chi; const double *const *Ms;
+    double *phi, *raw, *p0, *p1, *tf;
+    long nl[3];
+    double keff0, tol_keff, tol_flux, cg_tol; int cg_max, max_outer;
+    double ca1, a3[16], cb[16];
+    double *hist; int *hist_cg; ResidentOut *out;                // status 3: the workgroups did not assemble (nothing touched), 4: a barrier timed out
+};
+template <int NCH, bool VEC>
+__global__ __launch_bounds__(XCD_THREADS) void k_keff_xcd(XcdArgs A, XcdOuter O)
+{
+    extern __shared__ double sm[];
+    __shared__ int s_i[4];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *const sred = sm + 5 * 1024 + 64;
+    XcdCtx C; bool none;
+    const bool part = xcd_assemble(A.st, A.xcc, s_i, C, &none);
+    if (none) { O.out->keff = O.keff0; O.out->n_outer = 0; O.out->status = 3; O.out->cg_total = 0; }
+    if (!part) return;
+    xcd_plan(A, C, tid, wave, sm);
+    if (!C.ok) { if (C.widx == 0 && tid == 0) { O.out->keff = O.keff0; O.out->n_outer = 0; O.out->status = 3; O.out->cg_total = 0; } return; }
+    const int ng = O.ng; const long NP = O.NP, N = O.N, NT = NP * ng;
+    const long g0 = (long)C.widx * XCD_THREADS + tid, gs = (long)C.P * XCD_THREADS;
+    double keff = O.keff0;
+    int cheb_it = 0, n_outer = 0, status = 0, cg_total = 0;
+    double *pa = O.p0, *pb = O.p1;
+    long long xs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int it = 0; it < O.max_outer && !status; ++it) {
+        // total_fiss and prod_old (:1700-1707)
+        double v1[1] = { 0.0 };
+        for (long i = g0; i < NP; i += gs) {
+            double v = 0.0;
+            for (int g = 0; g < ng; ++g) v += O.Mf[g * NP + i] * __builtin_nontemporal_load(O.phi + g * NP + i);
+            O.tf[i] = v; v1[0] += v;
+        }
+        if (!xcd_total<1>(v1, A.part, A.st, C, sred, &s_i[3])) { status = 4; break; }
+        const double prod_old = v1[0];
+        const double inv_k = 1.0 / keff;
+        for (int g = 0; g < ng && !status; ++g) {
+            double *const graw = O.raw + (long)g * NP;
+            // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
+            v1[0] = 0.0;
+            for (long i = g0; i < NP; i += gs) {
+                double v = inv_k * (O.Chi[g * N + i] * __builtin_nontemporal_load(O.tf + i));
+                for (int gp = 0; gp < ng; ++gp) {
+                    const double *M = O.Ms[g * ng + gp];
+                    if (gp == g || !M) continue;
+                    v += M[i] * __builtin_nontemporal_load((gp < g ? O.raw : O.phi) + gp * NP + i);
+                }
+                graw[i] = 0.0; A.r[i] = v; A.pA[i] = v; v1[0] += v * v;
+            }
+            if (!xcd_total<1>(v1, A.part, A.st, C, sred, &s_i[3])) { status = 4; break; }
+            double rr = v1[0];
+            const double rhs_norm = sqrt(rr), tol_sq = O.cg_tol * O.cg_tol * rhs_norm * rhs_norm;
+            int its = 0, err = 0;
+            xcd_cg<NCH, VEC>(A, C, g * N, g * NP, g * O.nl[0], g * O.nl[1], g * O.nl[2], graw, rr, tol_sq, O.cg_max, its, err, sred, &s_i[3], xs);
+            if (err == 4) { status = 4; break; }
+            if (err == 1) status = 2;                             // a non-finite sum: the outer iteration below reports the divergence
+            if (tid == 0 && C.widx == 0) O.hist_cg[it * ng + g] = its;
+            cg_total += its;
+            if (!xcd_barrier(A.st, (unsigned)C.P * ++C.nbar, &s_i[3])) { status = 4; break; }   // this group's solution is complete before anybody reads it
+        }
+        if (status == 4) break;
+        // prod_new, norms (:1766-1779)
+        double v3[3] = { 0.0, 0.0, 0.0 };
+        for (long i = g0; i < NT; i += gs) { const double v = __builtin_nontemporal_load(O.raw + i), d = v - __builtin_nontemporal_load(O.phi + i); v3[0] += O.Mf[i] * v; v3[1] += v * v; v3[2] += d * d; }
+        if (!xcd_total<3>(v3, A.part, A.st, C, sred, &s_i[3])) { status = 4; break; }
+        const double prod_new = v3[0], nsq = v3[1], dsq = v3[2];
+        const double keff_new = keff * (prod_new / prod_old);
+        const double dk = fabs(keff_new - keff);
+        if (it >= 1) keff = keff_new;                               // :1774
+        const double dphi = sqrt(dsq / nsq), norm = sqrt(nsq);
+        if (tid == 0 && C.widx == 0) { O.hist[it] = keff; O.hist[O.max_outer + it] = dk; O.hist[2 * O.max_outer + it] = dphi; }
+        n_outer = it + 1;
+        if (!isfinite(keff_new) || !isfinite(dphi)) { status = 2; break; }
+        status = 0;
+        // normalise + Chebyshev (:1780-1788, src/solvers.cpp:720-756)
+        int mode = 0; double ca = 0.0, cb = 0.0;
+        if (it >= 2) {
+            if (cheb_it == 15) cheb_it = 0;
+            if (cheb_it == 0) mode = 1;
+            else if (cheb_it == 1) { mode = 2; ca = O.ca1; }
+            else { mode = 3; ca = O.a3[cheb_it]; cb = O.cb[cheb_it]; }
+            ++cheb_it;
+        }
+        const bool do_norm = norm > 1e-14;
+        for (long i = g0; i < NT; i += gs) {
+            double v = __builtin_nontemporal_load(O.raw + i);
+            if (do_norm) v /= norm;
+            if (mode == 1) pa[i] = v;
+            else if (mode == 2) { const double a = pa[i]; v = a + ca * (v - a); pb[i] = v; }
+            else if (mode == 3) { const double a = pa[i], b = pb[i]; v = b + ca * (v - b) + cb * (b - a); pa[i] = v; }
+            O.phi[i] = v;
+        }
+        if (mode == 3) { double *t = pa; pa = pb; pb = t; }
+        if (!xcd_barrier(A.st, (unsigned)C.P * ++C.nbar, &s_i[3])) { status = 4; break; }   // the new phi before the next fission source
+        if (dk < O.tol_keff && dphi < O.tol_flux) break;            // :1799-1802
+    }
+    if (tid == 0 && C.widx == 0) { O.out->keff = keff; O.out->n_outer = n_outer; O.out->status = status; O.out->cg_total = cg_total; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1980,7 +2148,6 @@ __global__ __launch_bounds__(256) void k_normalize_fission(const double *__restr
 // phase is separated by a workgroup barrier only; the direction passes are the same device functions as the big-mesh kernels
 // (schur_x_task, schur_s_tile: identical per-cell arithmetic), run over "virtual" tiles; reductions are fixed-order
 // (thread-strided, then wave, then across waves), so runs are reproducible; every thread derives the same scalars from them.
-struct ResidentOut { double keff; int n_outer, status, cg_total, pad; };   // status 0 ok, 2 diverged (non-finite k or dphi)
 struct ResidentArgs {
     Geom G; int ng, dim, nmodes; long N, nphi;
     ModeArgs ma[3]; ModeTab mt[3];          // per direction, mode 0, group 0, x -> p, y -> q; Cd and D advance with the group

@@ -1,5 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out/r03_x; mkdir -p $OUT
-timeout -k 10 400 python profiles/tools/xcd_sweep.py > $OUT/xcd_sweep.txt 2>&1; rc=$?; cat $OUT/xcd_sweep.txt | tail -30; echo "rc=$rc"
-[ $rc -ne 0 ] && exit 1
-timeout -k 10 240 python profiles/tools/xcd_dev.py 7 > $OUT/xcd_dev.txt 2>&1; rc=$?; cat $OUT/xcd_dev.txt | tail -30; echo "rc=$rc"
+# kernel trace of one IAEA-3D 38x38x19 solve as the driver runs it (coarse start): where does the time outside k_keff_xcd go?
+OUT=$PWD/gpurun_out/r03_x; mkdir -p $OUT; REPO=$PWD
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 $REPO/profiles/tools/r02/small_trace.py iaea3d 0 1 > $OUT/trace.log 2>&1; rc=$?; tail -3 $OUT/trace.log; echo "rc=$rc"
+cd $REPO; python3 profiles/tools/r02/trace_gaps.py $OUT/trace > $OUT/trace_gaps.txt 2>&1; cat $OUT/trace_gaps.txt

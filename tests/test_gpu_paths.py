@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=0), 0), ("resident", dict(resident=1, resident_max_dofs=100000), 2),
          # whole CG solve in one launch on one XCD, forced onto every RT0-P0 mesh it can take; and the same aimed at an XCD that does not
          # exist: nobody registers, the kernel reports it before touching a vector and the solver carries on through the launches
-         ("xcd", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=1, cg_xcd_min_cells=0, cg_xcd_max_cells=1 << 30), 0),
+         ("xcd", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=1, keff_xcd=0, cg_xcd_min_cells=0, cg_xcd_max_cells=1 << 30), 0),
+         # the whole power iteration in the same kind of launch (k_keff_xcd; nf_info last_path 3 where it can run)
+         ("xcd-keff", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=1, keff_xcd=1, cg_xcd_min_cells=0, cg_xcd_max_cells=1 << 30), 3),
          ("xcd-refused", dict(resident=0, cg_fuse3=1, cg_fuse3_max_cells=4 << 20, cg_xcd=1, cg_xcd_min_cells=0, cg_xcd_max_cells=1 << 30, cg_xcd_id=9), 0),
          ("resident-scans", dict(resident=1, resident_max_dofs=100000, resident_serial=0), 2),
          ("resident-one-sided", dict(resident=1, resident_max_dofs=100000, resident_two_sided=0), 2),   # one lane per line instead of a pair meeting in the middle
@@ -41,7 +43,7 @@ def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
 def _check_xcd(name, r, shape, p):
     """k_cg_xcd ran where it can (P0 flux: one unknown per cell, RT0-P0 and RT1-P0; x lines of at most 128 cells) and only where it was asked to"""
     can = p == 0 and shape[0] <= 128
-    if name == "xcd":
+    if name in ("xcd", "xcd-keff"):
         assert (r["xcd"] > 0) == can and r["refused"] == 0, (name, r["xcd"], r["refused"])
     elif name == "xcd-refused":
         assert r["xcd"] == 0 and r["refused"] == (1 if can else 0), (name, r["xcd"], r["refused"])
@@ -67,6 +69,8 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         r = res[name] = _run(inp, rt, p, tol, opts)
         if name == "resident-scans" and shape[0] > 128:
             path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
+        if name == "xcd-keff" and not (p == 0 and shape[0] <= 128):
+            path = 0
         assert r["path"] == path, (name, r["path"])
         _check_xcd(name, r, shape, p)
         assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
@@ -75,7 +79,7 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     assert res["classic-streaming"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-streaming"]["phi"], res["classic"]["phi"])   # same arithmetic, other load instructions
     assert res["classic-no-host-page"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-no-host-page"]["phi"], res["classic"]["phi"])   # readback route only
     assert res["xcd-refused"]["k"] == res["fuse3"]["k"] and np.array_equal(res["xcd-refused"]["phi"], res["fuse3"]["phi"])   # the fall-back IS the launch path
-    for name in ("fuse3", "xcd", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
+    for name in ("fuse3", "xcd", "xcd-keff", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
         if name not in res:
             continue
         assert abs(res[name]["k"] - res["classic"]["k"]) / ko < 1e-10
@@ -96,6 +100,8 @@ def test_paths_fixed_work_histories(shape, rt, ng):
             path = 0
         if name.startswith("big-") and (rt > 0 or shape[1] == 1):
             continue
+        if name == "xcd-keff" and not (rt == 0 and shape[0] <= 128):
+            path = 0
         r = _run(inp, rt, rt, tol, opts)
         assert r["path"] == path and r["n"] == 6, (name, r["path"], r["n"])
         _check_xcd(name, r, shape, rt)
@@ -111,6 +117,8 @@ def test_paths_on_benchmarks_with_driver_settings(name, rt):
     o = make_oracle(inp, rt, rt); o.set_tol(*TEST_TOL); ko = o.SolveKeff(True, f); ho = o.history()
     for pname, opts, path in PATHS:
         r = _run(inp, rt, rt, TEST_TOL, opts, True, f)
+        if pname == "xcd-keff" and rt > 0:
+            path = 0
         assert r["path"] == path
         assert r["n"] == ho["n_outer"], (pname, r["n"], ho["n_outer"])
         assert np.array_equal(r["cg"], ho["cg"]), (pname, r["cg"].ravel(), ho["cg"].ravel())

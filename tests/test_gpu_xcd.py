@@ -1,4 +1,4 @@
-"""k_cg_xcd: the whole CG solve (src/solvers.cpp:577-636) of a mid-size mesh with one unknown per cell in ONE launch on the workgroups of one
+"""k_cg_xcd / k_keff_xcd: the whole CG solve (src/solvers.cpp:577-636) of a mid-size mesh with one unknown per cell in ONE launch on the workgroups of one
 XCD.  It is the default between 2 000 and 28 000 cells; these tests run it there, with default options, against the
 oracle -- tests/test_gpu_paths.py forces it onto the small shapes of the path matrix as well."""
 import numpy as np
@@ -24,7 +24,7 @@ def test_default_path_in_the_window_matches_the_oracle(shape, rt, ng):
     for _ in range(2):
         s = make_hip(inp, rt, 0); s.set_tol(*tol)
         k, n = s.solve_keff()
-        assert s.info("last_path") == 0 and s.info("xcd_solves") == 6 * ng and s.info("xcd_refused") == 0
+        assert s.info("last_path") == 3 and s.info("xcd_solves") == 6 * ng and s.info("xcd_refused") == 0     # k_keff_xcd: the whole power iteration
         runs.append((k, s.get_phi().copy(), s.history()["k"].copy(), s.get_J().copy(), s.history()["cg"].copy()))
         s.close()
     k, phi, hk, J, cg = runs[0]
@@ -42,15 +42,16 @@ def test_iteration_cap_and_launch_path_agree():
     tol = (0.0, 1e-13, 1e-13, 4, 9)                                # 9 CG iterations per group solve, never converged
     o = make_oracle(inp); o.set_tol(*tol); o.SolveKeff(); ho = o.history()
     res = {}
-    for xcd in (1, 0):
-        s = make_hip(inp); s.set_tol(*tol); s.set_option("cg_xcd", xcd)
+    for xcd, whole in ((1, 1), (1, 0), (0, 0)):
+        s = make_hip(inp); s.set_tol(*tol); s.set_option("cg_xcd", xcd); s.set_option("keff_xcd", whole)
         k, n = s.solve_keff()
-        assert (s.info("xcd_solves") > 0) == bool(xcd)
+        assert (s.info("xcd_solves") > 0) == bool(xcd) and s.info("last_path") == (3 if whole else 0)
         assert np.all(s.history()["cg"] == 9) and np.all(ho["cg"] == 9)
         np.testing.assert_allclose(s.history()["k"], ho["k"], rtol=1e-9)
-        res[xcd] = (k, s.get_phi().copy())
+        res[xcd + whole] = (k, s.get_phi().copy())
         s.close()
-    assert abs(res[1][0] - res[0][0]) < 1e-12 and rel_l2(res[1][1], res[0][1]) < 1e-11
+    for a in (1, 2):                                                # k_cg_xcd under the host's outer loop, k_keff_xcd: both against the launches
+        assert abs(res[a][0] - res[0][0]) < 1e-12 and rel_l2(res[a][1], res[0][1]) < 1e-11
 
 
 def test_refused_start_falls_back_within_the_solve():
