@@ -195,7 +195,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   "cg_xcd" (default 1) runs every CG solve of an undivided mesh with one unknown per cell and "cg_xcd_min_cells" .. "cg_xcd_max_cells"
  *   cells (default 2000 .. 28000) as ONE launch on the workgroups of XCD "cg_xcd_id" (default 0; 8..15 name none: the solve falls back,
  *   for tests), "cg_xcd_groups" (default 32) workgroups per XCD being launched; nf_info "xcd_solves" counts its solves, "xcd_refused"
- *   the times its workgroups did not assemble and the launch path took over;
+ *   the times its workgroups did not assemble and the launch path took over; "keff_xcd" (default 1) runs the whole SolveKeff of such a mesh
+ *   (iterative full-Schur path, no CMFD) in one launch of the same kind (nf_info "last_path" 3);
  *   "resident" (default 1) runs the whole SolveKeff of an undivided mesh with at most "resident_max_dofs" flux DOFs per group (default
  *   2500) in one workgroup and one launch; "resident_lds" (default 1) keeps its CG vectors and factors in LDS as far as they fit;
  *   "resident_serial" (default 1): meshes whose moments, factors and directions' contributions all fit in LDS run one lane per
@@ -211,7 +212,7 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   256 MB memory-side cache between launches) the direction passes read their streams with non-temporal loads;
  *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
  *   "sep_fold" (default 1): slab teams form the separator values inside the accumulation pass of the z lines (no k_separators launch).
- * nf_info keys beyond the mesh sizes: "last_path" (0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel),
+ * nf_info keys beyond the mesh sizes: "last_path" (0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel, 3 one-XCD kernel),
  * "last_direct" (0 CG as configured, 1 dense S^-1, 2 CG to 1e-14 standing in). */
 int nf_set_option(nf_handle h, const char *key, long value);
 
