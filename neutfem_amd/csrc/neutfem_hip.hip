@@ -3192,13 +3192,13 @@ int nf_memcpy_d2h(nf_handle S, void *dst, const void *src, size_t bytes)
 int nf_synchronize(nf_handle S) { if (!S) return fail(NF_ERR_ARG, "null handle"); HIPCHK(hipSetDevice(S->device)); HIPCHK(hipStreamSynchronize(S->team->stream)); HIPCHK(hipDeviceSynchronize()); return NF_OK; }
 void *nf_stream(nf_handle S) { return S ? (void *)S->team->stream : nullptr; }
 
-// diagnostic (not part of the C ABI): the partial / stamp buffer of k_cg_xcd (doubles 128.. hold cycle stamps in -DNF_XSTAMPS builds)
+// diagnostic (not part of the C ABI): the partial / stamp buffer of k_cg_xcd (doubles 384.. hold s_memrealtime sums in -DNF_XSTAMPS builds)
 extern "C" int nf_debug_xcd_buffer(void *h, double *out, int n, int coarse)
 {
     nf_solver *S = (nf_solver *)h; if (!S || !S->team) return NF_ERR_ARG;
     nf_team *T = S->team;
     (void)coarse;
     if (!T->d_xpart) { for (int i = 0; i < n; ++i) out[i] = 0.0; return NF_OK; }
-    HIPCHK(hipMemcpy(out, T->d_xpart, sizeof(double) * std::min(n, 256), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, T->d_xpart, sizeof(double) * std::min(n, 512), hipMemcpyDeviceToHost));
     return NF_OK;
 }
