@@ -138,6 +138,7 @@ def small_configs(device):
         for _ in range(3):
             s.reset_flux(); t0 = time.perf_counter(); k, n = s.solve_keff(coarse, f, diag); best = min(best, time.perf_counter() - t0)
         h = s.history()
+        path = {0: "host-driven outer loop", 1: "diagonal device loop", 2: "resident one-workgroup kernel", 3: "one-XCD kernel"}.get(int(s.info("last_path")), "?")
         o = OracleNeutFEM(rt, rt, ng, z["x_breaks"], z["y_breaks"], z["z_breaks"]); setup(o, False)
         o.get_D()[...] = z["D"]; o.get_SigR()[...] = z["SigR"]; o.get_NSF()[...] = z["NSF"]; o.get_Chi()[...] = z["Chi"]; o.get_SigS()[...] = z["SigS"]
         o.BuildMatrices(); o.set_tol(1e-5, 1e-4, 1e-4, 200, 1000)
@@ -146,7 +147,7 @@ def small_configs(device):
             o.reset_flux(); t0 = time.perf_counter(); ko = o.SolveKeff(coarse, f if coarse else [], diag); tcpu = min(tcpu, time.perf_counter() - t0)
         pg, po = s.get_phi().ravel(), o.phi_dofs().ravel()
         ho = o.history()
-        res.append(dict(config=label, cells=int(s.ne), outers=int(n), coarse_outers=int(h["coarse_outer"]), cg_iterations=int(h["cg"].sum()),
+        res.append(dict(config=label, cells=int(s.ne), path=path, outers=int(n), coarse_outers=int(h["coarse_outer"]), cg_iterations=int(h["cg"].sum()),
                         outers_oracle=int(ho["n_outer"]), cg_iterations_oracle=int(ho["cg"].sum()),
                         flux_rel_l2_vs_oracle=float(_np.linalg.norm(pg - po) / _np.linalg.norm(po)),
                         solve_ms=round(best * 1e3, 2), outer_iters_per_s=round(n / best, 1), keff=k, keff_oracle=ko,
