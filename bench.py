@@ -285,19 +285,24 @@ def main():
     traffic, traffic_source = None, None
     try:
         import re
-        def _tag(fn):                                               # r02_a_... -> (2, "a"); r01_... -> (1, "")
-            m = re.match(r"r(\d+)_(?:([a-z])_)?", fn)
-            return (int(m.group(1)), m.group(2) or "") if m else (0, "")
-        prof = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_256cube.json")), key=_tag)[-1]
-        with open(os.path.join(ROOT, "profiles", prof)) as f:
-            pj = json.load(f)
+        def _tag(fn):                                               # r02_a_... -> (2, 1, "a"); r03_zz_... -> (3, 2, "zz"); r01_... -> (1, 0, "")
+            m = re.match(r"r(\d+)_(?:([a-z]+)_)?", fn)
+            return (int(m.group(1)), len(m.group(2) or ""), m.group(2) or "") if m else (0, 0, "")
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from summarize import kernel_source_hash
+        cur = kernel_source_hash()
+        cands = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_256cube.json")), key=_tag)
+        def _load(fn):
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                return json.load(f)
+        fresh_ones = [f for f in cands if _load(f).get("kernel_source_sha256") == cur]     # the profile of THESE kernels if there is one, else the latest
+        prof = fresh_ones[-1] if fresh_ones else cands[-1]
+        pj = _load(prof)
         pmc = pj["kernels"]
         pat = {"schur_x": r"k_schur_x<", "schur_y": r"k_schur_[sc]<(\d+, )?1,", "schur_z": r"k_schur_[sc]<(\d+, )?2,", "schur_apply": r"k_apply3<"}[dom["name"]]
         hits = [k for k in pmc if re.match(pat, k)]
         key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None
-        sys.path.insert(0, os.path.join(ROOT, "profiles"))
-        from summarize import kernel_source_hash
-        fresh = pj.get("kernel_source_sha256") == kernel_source_hash()
+        fresh = pj.get("kernel_source_sha256") == cur
         if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc and not fresh:
             # the newest committed profile was taken with other kernel sources: no figure rather than a stale one
             traffic_source = dict(file="profiles/" + prof, stale=True, why="the device kernels changed since this profile was collected (sha256 of nf_kernels.h differs): traffic = null")
