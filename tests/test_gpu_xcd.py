@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 # inside the default window: 3D with all three roles in one round, 3D that needs two chunks per lane on its x lines (33..64 cells),
 # 2D, 1D, RT1-P0 (P0 flux, RT1 currents), an odd x length (scalar loads instead of pairs)
-SHAPES = [((30, 28, 9), 0, 2), ((38, 30, 12), 0, 2), ((64, 48, 1), 0, 2), ((100, 90, 1), 0, 3), ((23, 21, 17), 0, 2), ((40, 30, 4), 1, 2)]
+SHAPES = [((30, 28, 9), 0, 2), ((38, 30, 12), 0, 2), ((64, 48, 1), 0, 2), ((100, 90, 1), 0, 3), ((23, 21, 17), 0, 2), ((40, 30, 4), 1, 2),
+          ((37, 35, 19), 0, 2)]                                    # x lines of 37 cells in two chunks per lane, odd length: k_keff_xcd<2, false>
 
 
 @pytest.mark.parametrize("shape,rt,ng", SHAPES)
@@ -69,3 +70,18 @@ def test_refused_start_falls_back_within_the_solve():
         s.close()
     assert out[1][2] == 0 and out[1][3] == 1 and out[0][3] == 0
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
+def test_two_rounds_beyond_the_window():
+    """a mesh past the default window (forced): the three roles of a workgroup no longer fit its wavefronts at once and phase A takes two
+    rounds -- slower than the launches there, but it must still be right"""
+    inp = synthetic_inputs(40, 36, 30, 2, seed=29)
+    tol = (0.0, 1e-11, 1e-11, 3, 5000)
+    o = make_oracle(inp); o.set_tol(*tol); o.SolveKeff(); ho = o.history()
+    s = make_hip(inp); s.set_tol(*tol); s.set_option("cg_xcd_max_cells", 1 << 30)
+    k, n = s.solve_keff()
+    assert s.info("last_path") == 3 and s.info("xcd_solves") == 6 and s.info("xcd_refused") == 0
+    np.testing.assert_allclose(s.history()["k"], ho["k"], rtol=1e-9)
+    assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8
+    s.close()
+
