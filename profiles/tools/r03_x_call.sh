@@ -1,3 +1,7 @@
 #!/bin/bash
 OUT=gpurun_out/r03_x; mkdir -p $OUT
-timeout -k 10 600 python profiles/tools/xcd_fuzz.py 60 1 > $OUT/xcd_fuzz.txt 2>&1; rc=$?; tail -70 $OUT/xcd_fuzz.txt; echo "rc=$rc"
+(while true; do sleep 60; echo "[heartbeat $(date +%H:%M:%S)] $(tail -c 100 $OUT/pytest_dur.txt 2>/dev/null | tr '\n' ' ')"; done) &
+HB=$!
+timeout -k 10 1100 python -m pytest tests -q -m gpu --durations=60 > $OUT/pytest_dur.txt 2>&1; rc=$?
+kill $HB
+tail -75 $OUT/pytest_dur.txt; echo "rc=$rc"
