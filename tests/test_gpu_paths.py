@@ -66,6 +66,8 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
     for name, opts, path in PATHS:
         if name.startswith("big-") and (rt > 0 or shape[1] == 1):
             continue                                                # split dot / chunked lines exist for RT0-P0 y / z passes only: elsewhere these options change nothing
+        if shape[0] * shape[1] * shape[2] > 3000 and name in ("resident-one-sided", "big-whole-dot", "big-split-dot"):
+            continue                                                # the largest shape (a minute of solves): these three differ from a neighbour by one switch that 16 smaller shapes cover
         r = res[name] = _run(inp, rt, p, tol, opts)
         if name == "resident-scans" and shape[0] > 128:
             path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
