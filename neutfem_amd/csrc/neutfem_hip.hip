@@ -1407,8 +1407,9 @@ static int launch_apply3(nf_solver *S, int g, const Fuse3Plan &P, const double *
 // CgScalars hold the outcome of FIN_RHS, r = p = rhs, x = 0.  One launch; the kernel publishes the final scalars to the host itself.
 static bool xcd_eligible(const nf_team *T, const nf_solver *S, const Fuse3Plan &P)
 {
-    if (!T->opt_cgx || !P.ok || S->nb != 0 || S->nloc != 1 || n_modes(S) != 1 || T->profile) return false;   // one unknown per cell (P0 flux)
-    if (S->N < T->xcd_min_cells || S->N > T->xcd_max_cells) return false;
+    if (!T->opt_cgx || !P.ok || T->profile) return false;
+    if (S->nb == 0 ? (S->nloc != 1 || n_modes(S) != 1) : (P.seg != 4 || n_modes(S) > 9 || S->nb > 2)) return false;   // P0 flux: one unknown per cell; bubble moments: the SEG = 4 tiles
+    if (S->nphi < T->xcd_min_cells || S->nphi > T->xcd_max_cells) return false;                                      // the window counts unknowns per group
     for (int r = 0; r < 2; ++r) if (S->dim >= r + 2 && (P.A.NSEG[r] >= 64 || P.A.TX[r] * P.A.NSEG[r] > 448)) return false;   // no wavefront scan in the packed tiles; a tile fits beside the other roles
     return S->nx <= 128;                                          // x lines: at most two chunks per lane (128 VGPRs at 1024 threads)
 }
@@ -1428,6 +1429,8 @@ static int xcd_fill(nf_solver *S, int g, const Fuse3Plan &P, XcdArgs &A, int *nc
         A.L[d] = S->d_L[dd] + g * N; A.DR[d] = S->d_DR[dd] + g * N; A.D0[d] = S->d_D0[dd] + g * S->nlines[dd]; A.q[d] = qd[dd];
     }
     A.nx = S->nx; A.ny = S->ny; A.dim = S->dim; A.nlines_x = S->nlines[0]; A.N = S->nphi;
+    A.nmodes = n_modes(S);
+    for (int d = 0; d < 3; ++d) A.mt[d] = mode_tab(S, d < S->dim ? d : 0);
     // x lines: few wavefronts matter more here than short scans (the roles share the 12 wavefronts of a workgroup, and a second round
     // costs a whole memory round trip): two chunks per lane from 33 cells on -- 38 cells = 16 lanes x 2 cells x 2 chunks, four lines
     // per wavefront, where the launch path takes 32 lanes and two lines
@@ -1436,9 +1439,9 @@ static int xcd_fill(nf_solver *S, int g, const Fuse3Plan &P, XcdArgs &A, int *nc
     int nch = (lanes + (1 << lpl_log2) - 1) >> lpl_log2;
     if (nch == 1 && lpl_log2 == 5) {
         // 32 lanes, one chunk (the shorter chain) if the three roles of a workgroup still fit its wavefronts in one round
-        const int Pn = T->xcd_groups, tasks = (int)((S->nlines[0] + 1) / 2);
+        const int Pn = T->xcd_groups, tasks = (int)((S->nlines[0] + 1) / 2) * A.nmodes;
         int waves = (tasks + Pn - 1) / Pn;
-        for (int r = 0; r < 2; ++r) if (S->dim >= r + 2) waves += (((P.A.gx[r] * P.A.gy[r] + Pn - 1) / Pn) * P.A.TX[r] * P.A.NSEG[r] + 63) / 64;
+        for (int r = 0; r < 2; ++r) if (S->dim >= r + 2) waves += (((P.A.gx[r] * P.A.gy[r] * A.nmodes + Pn - 1) / Pn) * P.A.TX[r] * P.A.NSEG[r] + 63) / 64;
         if (waves > XCD_THREADS / 64) { lpl_log2 = 4; nch = 2; }
     }
     if (nch > 2) return fail(NF_ERR_STATE, "k_cg_xcd: x lines of %d cells", S->nx);
@@ -1459,10 +1462,12 @@ static int launch_cg_xcd(nf_solver *S, int g, const Fuse3Plan &P, double *xsol, 
     A.xsol = xsol; A.cg = T->d_cg; A.hp = T->d_pub; A.seq = seq;
     const size_t lds = XCD_LDS;
     const unsigned G = 8u * (unsigned)T->xcd_groups;
-#define NF_XCD(NCHV, VECV) do { if (!lds_opt_in((const void *)k_cg_xcd<NCHV, VECV>, lds)) return fail(NF_ERR_HIP, "k_cg_xcd: %zu bytes of LDS refused", lds); \
-        hipLaunchKernelGGL((k_cg_xcd<NCHV, VECV>), dim3(G), dim3(XCD_THREADS), lds, st, A); } while (0)
-    if (nch == 1) { if (P.vec) NF_XCD(1, true); else NF_XCD(1, false); }
-    else { if (P.vec) NF_XCD(2, true); else NF_XCD(2, false); }
+#define NF_XCD(NCHV, VECV, NBV, SEGV) do { if (!lds_opt_in((const void *)k_cg_xcd<NCHV, VECV, NBV, SEGV>, lds)) return fail(NF_ERR_HIP, "k_cg_xcd: %zu bytes of LDS refused", lds); \
+        hipLaunchKernelGGL((k_cg_xcd<NCHV, VECV, NBV, SEGV>), dim3(G), dim3(XCD_THREADS), lds, st, A); } while (0)
+#define NF_XCD_NB(NCHV, VECV) do { if (S->nb == 0) NF_XCD(NCHV, VECV, 0, 8); else if (S->nb == 1) NF_XCD(NCHV, VECV, 1, 4); else NF_XCD(NCHV, VECV, 2, 4); } while (0)
+    if (nch == 1) { if (P.vec) NF_XCD_NB(1, true); else NF_XCD_NB(1, false); }
+    else { if (P.vec) NF_XCD_NB(2, true); else NF_XCD_NB(2, false); }
+#undef NF_XCD_NB
 #undef NF_XCD
     HIPCHK(hipGetLastError());
     return NF_OK;
@@ -2598,10 +2603,12 @@ static int solve_keff_xcd(nf_team *T, const nf_keff_opts *o, const Fuse3Plan &P,
     O.hist = T->d_hist; O.hist_cg = T->d_hist_cg; O.out = T->d_rout;
     const size_t lds = XCD_LDS;
     const unsigned G = 8u * (unsigned)T->xcd_groups;
-#define NF_XK(NCHV, VECV) do { if (!lds_opt_in((const void *)k_keff_xcd<NCHV, VECV>, lds)) return NF_RESIDENT_UNAVAILABLE; \
-        hipLaunchKernelGGL((k_keff_xcd<NCHV, VECV>), dim3(G), dim3(XCD_THREADS), lds, st, A, O); } while (0)
-    if (nch == 1) { if (P.vec) NF_XK(1, true); else NF_XK(1, false); }
-    else { if (P.vec) NF_XK(2, true); else NF_XK(2, false); }
+#define NF_XK(NCHV, VECV, NBV, SEGV) do { if (!lds_opt_in((const void *)k_keff_xcd<NCHV, VECV, NBV, SEGV>, lds)) return NF_RESIDENT_UNAVAILABLE; \
+        hipLaunchKernelGGL((k_keff_xcd<NCHV, VECV, NBV, SEGV>), dim3(G), dim3(XCD_THREADS), lds, st, A, O); } while (0)
+#define NF_XK_NB(NCHV, VECV) do { if (S->nb == 0) NF_XK(NCHV, VECV, 0, 8); else if (S->nb == 1) NF_XK(NCHV, VECV, 1, 4); else NF_XK(NCHV, VECV, 2, 4); } while (0)
+    if (nch == 1) { if (P.vec) NF_XK_NB(1, true); else NF_XK_NB(1, false); }
+    else { if (P.vec) NF_XK_NB(2, true); else NF_XK_NB(2, false); }
+#undef NF_XK_NB
 #undef NF_XK
     HIPCHK(hipGetLastError());
     ResidentOut ro;

@@ -952,10 +952,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
         if (i < SEG) Lv[i] = ok ? ldg<NT>(L + a) : 0.0; else Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
         if (NB > 0) {
-            v1a[i] = ok ? ma.x[1][a] : 0.0;
-            if (NB > 1) v2a[NB > 1 ? i : 0] = ok ? ma.x[2][a] : 0.0;
-            r1[i] = (!SLAB && fro && ok) ? ma.x[1][a + roff] : 0.0;
-            if (NB > 1) r2[NB > 1 ? i : 0] = (!SLAB && fro && ok) ? ma.x[2][a + roff] : 0.0;
+            v1a[i] = ok ? ldg<XC>(ma.x[1] + a) : 0.0;
+            if (NB > 1) v2a[NB > 1 ? i : 0] = ok ? ldg<XC>(ma.x[2] + a) : 0.0;
+            r1[i] = (!SLAB && fro && ok) ? ldg<XC>(ma.x[1] + a + roff) : 0.0;
+            if (NB > 1) r2[NB > 1 ? i : 0] = (!SLAB && fro && ok) ? ldg<XC>(ma.x[2] + a + roff) : 0.0;
             if (i < SEG) Dv[i] = ok ? ma.D[a] : 0.0;
         }
     }
@@ -1535,6 +1535,7 @@ struct XcdArgs {
     int nx, ny, dim; long nlines_x, N;
     int ntask_x, lpl_log2;
     int n[2], TX[2], NSEG[2], gx[2], gy[2]; long sl[2], ostride[2];   // y (0) and z (1) tiles
+    ModeTab mt[3]; int nmodes;                                        // transverse modes of every direction (orders with bubble moments; one mode for P0)
     double *pA, *pB, *r, *xsol; const double *q[3];
     CgScalars *cg; double *part;                                      // part: 4 rotating slots of 64 partials (xcd_total), then p.q | |r|^2 partials of the CG, then diagnostics: 512 doubles
     XcdState *st; HostPub *hp; unsigned long long seq; int xcc;
@@ -1594,8 +1595,8 @@ __device__ __forceinline__ void xcd_plan(const XcdArgs &A, XcdCtx &C, int tid, i
 {
     const int P = C.P, dim = A.dim;
     const int Ty = A.TX[0] * A.NSEG[0], Tz = A.TX[1] * A.NSEG[1];
-    const int nty = dim >= 2 ? A.gx[0] * A.gy[0] : 0, ntz = dim == 3 ? A.gx[1] * A.gy[1] : 0;
-    const int dx = (A.ntask_x + P - 1) / P, ty = (nty + P - 1) / P, tz = (ntz + P - 1) / P;
+    const int nty = dim >= 2 ? A.gx[0] * A.gy[0] * A.nmodes : 0, ntz = dim == 3 ? A.gx[1] * A.gy[1] * A.nmodes : 0;
+    const int dx = (A.ntask_x * A.nmodes + P - 1) / P, ty = (nty + P - 1) / P, tz = (ntz + P - 1) / P;
     int R = 1, wx = 0, wy = 0, wz = 0, cy = 0, cz = 0;
     for (;; ++R) {
         wx = (dx + R - 1) / R; cy = (ty + R - 1) / R; cz = (tz + R - 1) / R;
@@ -1638,7 +1639,9 @@ __device__ __forceinline__ bool xcd_total(double (&v)[NV], double *part, XcdStat
 // The CG solve of one group (src/solvers.cpp:577-636) by the assembled workgroups: x_sol = 0, r = p = rhs in pA and |rhs|^2 = rr are
 // in place.  offN / offP / offL*: this group's offsets into the factor arrays (cells), the C diagonal (unknowns) and the first pivots (lines).
 // err: 0, 1 (non-finite sum), 4 (a barrier timed out).  On return x_sol holds the solution (the deferred last update applied).
-template <int NCH, bool VEC>
+// NB > 0 (bubble moments): the wave-tasks and tiles of all transverse modes are numbered mode-major (ModeTab), y and z tiles run their own
+// instantiations (the bubbles' geometry factor depends on the direction) with SEG = 4 cells per thread.
+template <int NCH, bool VEC, int NB, int SEG>
 __device__ __forceinline__ void xcd_cg(const XcdArgs &A, XcdCtx &C, long offN, long offP, long offL0, long offL1, long offL2, double *xsol,
                                        double &rr, double tol_sq, int maxit, int &its, int &err, double *sred, int *s_ok, long long *xs)
 {
@@ -1647,7 +1650,10 @@ __device__ __forceinline__ void xcd_cg(const XcdArgs &A, XcdCtx &C, long offN, l
     SlabArgs sa0; sa0.if_lo = sa0.if_hi = sa0.mode = sa0.xcd = sa0.wsmin = sa0.fold = sa0.noacc = 0; sa0.yadd = nullptr; sa0.alo = sa0.ahi = sa0.ulo = sa0.uhi = sa0.rlo = sa0.rhi = sa0.sinv_lo = sa0.sinv_hi = nullptr; sa0.clo = sa0.chi = sa0.jz = sa0.jzb = nullptr; sa0.nfa = 1; sa0.ni = 0;
     const double *const sL = (C.isz ? A.L[2] : A.L[1]) + offN, *const sDR = (C.isz ? A.DR[2] : A.DR[1]) + offN, *const sD0 = C.isz ? A.D0[2] + offL2 : A.D0[1] + offL1;
     ModeArgs ms = A.ma[0]; ms.Ta = C.isz ? A.ma[2].Ta : A.ma[1].Ta; ms.y[0] = C.isz ? A.ma[2].y[0] : A.ma[1].y[0];
-    ModeArgs mx = A.ma[0]; mx.Cd[0] = A.ma[0].Cd[0] + offP;
+    ModeArgs mx = A.ma[0], my = A.ma[1], mz = A.ma[2];
+#pragma unroll
+    for (int q = 0; q <= NB; ++q) mx.Cd[q] = A.ma[0].Cd[q] + offP;
+    mx.D = A.ma[0].D + offN; my.D = A.ma[1].D + offN; mz.D = A.ma[2].D + offN;
     double alpha = 0.0, beta = 0.0, rr_new = rr;
     int pend = 0;
     double *const ppq = A.part + 256, *const prr = A.part + 320;
@@ -1671,15 +1677,38 @@ __device__ __forceinline__ void xcd_cg(const XcdArgs &A, XcdCtx &C, long offN, l
                     const int k = ro * C.sC + C.sSlot, t = widx * C.sPer + k;
                     const bool act = C.sSlot < C.sC && k < C.sPer && t < C.sNt;
                     const unsigned tt = act ? t : 0;
-                    ms.x[0] = pin;
-                    dot += schur_s_tile<8, 1, false, 0, true, false, NoMid, false, true>(ms, A.G, sL, sDR, sD0, C.sN, C.sSl, C.sOst, A.nx, C.sTX, C.sNSEG, tt % C.sGx, tt / C.sGx, 0, C.sGy,
-                                                                                          C.sLtid, act, C.sSm, sa0, fz, false, fuse, alpha, beta, false);
+                    if (NB == 0) {
+                        ms.x[0] = pin;
+                        dot += schur_s_tile<8, 1, false, 0, true, false, NoMid, false, true>(ms, A.G, sL, sDR, sD0, C.sN, C.sSl, C.sOst, A.nx, C.sTX, C.sNSEG, tt % C.sGx, tt / C.sGx, 0, C.sGy,
+                                                                                              C.sLtid, act, C.sSm, sa0, fz, false, fuse, alpha, beta, false);
+                    } else {
+                        const unsigned per = (unsigned)(C.sGx * C.sGy), bz = tt / per, rem = tt - bz * per;
+                        if (C.role == 1) {
+                            ModeArgs m = my;
+#pragma unroll
+                            for (int q = 0; q <= NB; ++q) { m.x[q] = pin + (A.ma[1].x[q] - A.pA); m.Cd[q] = nullptr; }
+                            m = select_mode(m, A.mt[1], bz, NB + 1);
+                            dot += schur_s_tile<SEG, 1, false, NB, true, false, NoMid, false, true>(m, A.G, sL, sDR, sD0, C.sN, C.sSl, C.sOst, A.nx, C.sTX, C.sNSEG, rem % C.sGx, rem / C.sGx, bz, C.sGy,
+                                                                                                    C.sLtid, act, C.sSm, sa0, fz, false, fuse, alpha, beta, false);
+                        } else {
+                            ModeArgs m = mz;
+#pragma unroll
+                            for (int q = 0; q <= NB; ++q) { m.x[q] = pin + (A.ma[2].x[q] - A.pA); m.Cd[q] = nullptr; }
+                            m = select_mode(m, A.mt[2], bz, NB + 1);
+                            dot += schur_s_tile<SEG, 2, false, NB, true, false, NoMid, false, true>(m, A.G, sL, sDR, sD0, C.sN, C.sSl, C.sOst, A.nx, C.sTX, C.sNSEG, rem % C.sGx, rem / C.sGx, bz, C.sGy,
+                                                                                                    C.sLtid, act, C.sSm, sa0, fz, false, fuse, alpha, beta, false);
+                        }
+                    }
                 } else {
                     const int k = ro * C.wx + wave; const long gt = (long)widx * C.dx + k;
-                    const bool act = C.role == 0 && k < C.dx && gt < A.ntask_x;
-                    mx.x[0] = pin;
-                    dot += schur_x_task<2, NCH, VEC, 0, NoMid, true, true>(mx, A.G, A.L[0] + offN, A.DR[0] + offN, A.D0[0] + offL0, A.nx, A.ny, A.nlines_x, A.lpl_log2, 1, act ? gt : 0, lane, act,
-                                                                          fuse, alpha, beta, fz);
+                    const bool act = C.role == 0 && k < C.dx && gt < (long)A.ntask_x * A.nmodes;
+                    const int mode = act ? (int)(gt / A.ntask_x) : 0;
+                    ModeArgs m = mx;
+#pragma unroll
+                    for (int q = 0; q <= NB; ++q) m.x[q] = pin + (A.ma[0].x[q] - A.pA);
+                    if (NB > 0) m = select_mode(m, A.mt[0], mode, NB + 1);
+                    dot += schur_x_task<2, NCH, VEC, NB, NoMid, true, true>(m, A.G, A.L[0] + offN, A.DR[0] + offN, A.D0[0] + offL0, A.nx, A.ny, A.nlines_x, A.lpl_log2, 1,
+                                                                           act ? gt - (long)mode * A.ntask_x : 0, lane, act, fuse, alpha, beta, fz);
                     __syncthreads(); __syncthreads();           // the two barriers inside a y / z tile
                 }
                 __syncthreads();                                 // the tiles' scan arrays are reused by the next round
@@ -1727,7 +1756,7 @@ __device__ __forceinline__ void xcd_cg(const XcdArgs &A, XcdCtx &C, long offN, l
             xsol[i] = fma(alpha, __builtin_nontemporal_load(plast + i), __builtin_nontemporal_load(xsol + i));
     }
 }
-template <int NCH, bool VEC>
+template <int NCH, bool VEC, int NB = 0, int SEG = 8>
 __global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
 {
     extern __shared__ double sm[];
@@ -1748,7 +1777,7 @@ __global__ __launch_bounds__(XCD_THREADS) void k_cg_xcd(XcdArgs A)
     const double tol_sq = A.cg->tol_sq; const int maxit = A.cg->maxit;
     int its = 0, err = C.ok ? 0 : 3;
     long long xs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (C.ok && !A.cg->done) xcd_cg<NCH, VEC>(A, C, 0, 0, 0, 0, 0, A.xsol, rr, tol_sq, maxit, its, err, sred, &s_i[3], xs);
+    if (C.ok && !A.cg->done) xcd_cg<NCH, VEC, NB, SEG>(A, C, 0, 0, 0, 0, 0, A.xsol, rr, tol_sq, maxit, its, err, sred, &s_i[3], xs);
 #ifdef NF_XSTAMPS
     if (C.widx == 0 && tid == 0) { for (int k = 0; k < 7; ++k) A.part[384 + k] += (double)xs[k]; A.part[391] += its; A.part[392] += 1; A.part[393] = C.P; A.part[394] = C.R; A.part[395] = C.wx; }
 #endif
@@ -1775,7 +1804,7 @@ struct XcdOuter {
     double ca1, a3[16], cb[16];
     double *hist; int *hist_cg; ResidentOut *out;                // status 3: the workgroups did not assemble (nothing touched), 4: a barrier timed out
 };
-template <int NCH, bool VEC>
+template <int NCH, bool VEC, int NB = 0, int SEG = 8>
 __global__ __launch_bounds__(XCD_THREADS) void k_keff_xcd(XcdArgs A, XcdOuter O)
 {
     extern __shared__ double sm[];
@@ -1811,7 +1840,9 @@ __global__ __launch_bounds__(XCD_THREADS) void k_keff_xcd(XcdArgs A, XcdOuter O)
             // rhs = chi_g tf / k + scatter (Gauss-Seidel) (:1716-1726); CG start x = 0, r = p = rhs (src/solvers.cpp:583-592)
             v1[0] = 0.0;
             for (long i = g0; i < NP; i += gs) {
-                double v = inv_k * (O.Chi[g * N + i] * __builtin_nontemporal_load(O.tf + i));
+                double v;
+                if (NB == 0) v = inv_k * (O.Chi[g * N + i] * __builtin_nontemporal_load(O.tf + i));
+                else { const double cv = O.Chi[g * N + i % N] * inv_k; v = fabs(cv) < 1e-14 ? 0.0 : cv * __builtin_nontemporal_load(O.tf + i); }   // BuildFissionRHS, P >= 1 (:1539-1561)
                 for (int gp = 0; gp < ng; ++gp) {
                     const double *M = O.Ms[g * ng + gp];
                     if (gp == g || !M) continue;
@@ -1823,7 +1854,7 @@ __global__ __launch_bounds__(XCD_THREADS) void k_keff_xcd(XcdArgs A, XcdOuter O)
             double rr = v1[0];
             const double rhs_norm = sqrt(rr), tol_sq = O.cg_tol * O.cg_tol * rhs_norm * rhs_norm;
             int its = 0, err = 0;
-            xcd_cg<NCH, VEC>(A, C, g * N, g * NP, g * O.nl[0], g * O.nl[1], g * O.nl[2], graw, rr, tol_sq, O.cg_max, its, err, sred, &s_i[3], xs);
+            xcd_cg<NCH, VEC, NB, SEG>(A, C, g * N, g * NP, g * O.nl[0], g * O.nl[1], g * O.nl[2], graw, rr, tol_sq, O.cg_max, its, err, sred, &s_i[3], xs);
             if (err == 4) { status = 4; break; }
             if (err == 1) status = 2;                             // a non-finite sum: the outer iteration below reports the divergence
             if (tid == 0 && C.widx == 0) O.hist_cg[it * ng + g] = its;

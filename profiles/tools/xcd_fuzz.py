@@ -19,19 +19,24 @@ for c in range(cases):
     if nx * ny * nz < 220:                                          # below 200 unknowns the explicit-S branch takes over (no CG at all): 1D meshes
         ny = max(ny, 3)                                             # of at most 128 cells never reach the CG, so a tiny case becomes 2D
         if nx * ny * nz < 220: nx = max(nx, 80)
-    ng = int(rng.integers(1, 4)); rt = int(rng.choice([0, 0, 0, 1]))
+    ng = int(rng.integers(1, 4)); rt = int(rng.choice([0, 0, 1, 1, 2])); pm = int(rng.choice([0, rt])) if rt else 0
+    if pm > 0:                                                      # (m + 1)^dim unknowns per cell: keep the case small
+        while nx * ny * nz * (pm + 1) ** dim > 60000:
+            if nz > 2: nz = max(2, nz // 2)
+            elif ny > 2: ny = max(2, ny // 2)
+            else: nx = max(2, nx // 2)
     inp = synthetic_inputs(nx, ny, nz, ng, seed=100 + c)
     tol = (0.0, 1e-11, 1e-11, 4, 4000)
     res = {}
     for name, opts in (("launches", dict(cg_xcd=0)), ("cg", dict(cg_xcd=1, keff_xcd=0)), ("keff", dict(cg_xcd=1, keff_xcd=1))):
-        s = make_hip(inp, rt, 0); s.set_tol(*tol); s.set_option("resident", 0); s.set_option("cg_xcd_min_cells", 0); s.set_option("cg_xcd_max_cells", 1 << 30)
+        s = make_hip(inp, rt, pm); s.set_tol(*tol); s.set_option("resident", 0); s.set_option("cg_xcd_min_cells", 0); s.set_option("cg_xcd_max_cells", 1 << 30)
         for k_, v_ in opts.items():
             s.set_option(k_, v_)
         k, n = s.solve_keff()
         res[name] = (k, s.get_phi().copy(), s.info("xcd_solves"), s.info("last_path"), s.info("xcd_refused"), int(s.history()["cg"].sum()))
         s.close()
     ref = res["launches"]
-    line = f"case {c:3d}: {nx:3d} x {ny:2d} x {nz:2d} RT{rt}-P0 {ng}g  CG {ref[5]:5d}"
+    line = f"case {c:3d}: {nx:3d} x {ny:2d} x {nz:2d} RT{rt}-P{pm} {ng}g  CG {ref[5]:5d}"
     for name in ("cg", "keff"):
         r = res[name]
         dk = abs(r[0] - ref[0]) / abs(ref[0]); dphi = rel_l2(r[1], ref[1])

@@ -41,8 +41,8 @@ def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
 
 
 def _check_xcd(name, r, shape, p):
-    """k_cg_xcd ran where it can (P0 flux: one unknown per cell, RT0-P0 and RT1-P0; x lines of at most 128 cells) and only where it was asked to"""
-    can = p == 0 and shape[0] <= 128
+    """k_cg_xcd / k_keff_xcd ran where they can (every order; x lines of at most 128 cells) and only where they were asked to"""
+    can = shape[0] <= 128
     if name in ("xcd", "xcd-keff"):
         assert (r["xcd"] > 0) == can and r["refused"] == 0, (name, r["xcd"], r["refused"])
     elif name == "xcd-refused":
@@ -71,7 +71,7 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         r = res[name] = _run(inp, rt, p, tol, opts)
         if name == "resident-scans" and shape[0] > 128:
             path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
-        if name == "xcd-keff" and not (p == 0 and shape[0] <= 128):
+        if name == "xcd-keff" and shape[0] > 128:
             path = 0
         assert r["path"] == path, (name, r["path"])
         _check_xcd(name, r, shape, p)
@@ -102,7 +102,7 @@ def test_paths_fixed_work_histories(shape, rt, ng):
             path = 0
         if name.startswith("big-") and (rt > 0 or shape[1] == 1):
             continue
-        if name == "xcd-keff" and not (rt == 0 and shape[0] <= 128):
+        if name == "xcd-keff" and shape[0] > 128:
             path = 0
         r = _run(inp, rt, rt, tol, opts)
         assert r["path"] == path and r["n"] == 6, (name, r["path"], r["n"])
@@ -119,8 +119,6 @@ def test_paths_on_benchmarks_with_driver_settings(name, rt):
     o = make_oracle(inp, rt, rt); o.set_tol(*TEST_TOL); ko = o.SolveKeff(True, f); ho = o.history()
     for pname, opts, path in PATHS:
         r = _run(inp, rt, rt, TEST_TOL, opts, True, f)
-        if pname == "xcd-keff" and rt > 0:
-            path = 0
         assert r["path"] == path
         assert r["n"] == ho["n_outer"], (pname, r["n"], ho["n_outer"])
         assert np.array_equal(r["cg"], ho["cg"]), (pname, r["cg"].ravel(), ho["cg"].ravel())

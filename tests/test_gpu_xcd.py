@@ -1,5 +1,5 @@
 """k_cg_xcd / k_keff_xcd: the whole CG solve (src/solvers.cpp:577-636) of a mid-size mesh with one unknown per cell in ONE launch on the workgroups of one
-XCD.  It is the default between 2 000 and 28 000 cells; these tests run it there, with default options, against the
+XCD.  It is the default between 2 000 and 28 000 unknowns per group (every order); these tests run it there, with default options, against the
 oracle -- tests/test_gpu_paths.py forces it onto the small shapes of the path matrix as well."""
 import numpy as np
 import pytest
@@ -10,20 +10,22 @@ pytestmark = pytest.mark.gpu
 
 # inside the default window: 3D with all three roles in one round, 3D that needs two chunks per lane on its x lines (33..64 cells),
 # 2D, 1D, RT1-P0 (P0 flux, RT1 currents), an odd x length (scalar loads instead of pairs)
-SHAPES = [((30, 28, 9), 0, 2), ((38, 30, 12), 0, 2), ((64, 48, 1), 0, 2), ((100, 90, 1), 0, 3), ((23, 21, 17), 0, 2), ((40, 30, 4), 1, 2),
-          ((37, 35, 19), 0, 2)]                                    # x lines of 37 cells in two chunks per lane, odd length: k_keff_xcd<2, false>
+SHAPES = [((30, 28, 9), 0, 0, 2), ((38, 30, 12), 0, 0, 2), ((64, 48, 1), 0, 0, 2), ((100, 90, 1), 0, 0, 3), ((23, 21, 17), 0, 0, 2), ((40, 30, 4), 1, 0, 2),
+          ((37, 35, 19), 0, 0, 2),                                 # x lines of 37 cells in two chunks per lane, odd length: k_keff_xcd<2, false>
+          # orders with bubble moments (the window counts unknowns per group): RT1-P1 2D and 3D, RT2-P2, RT2-P1, x lines in two chunks
+          ((40, 30, 1), 1, 1, 2), ((14, 12, 6), 1, 1, 2), ((30, 26, 1), 2, 2, 2), ((48, 30, 1), 2, 1, 1), ((70, 20, 1), 1, 1, 2)]      # (beyond the 5120 unknowns the one-workgroup resident kernel takes)
 
 
-@pytest.mark.parametrize("shape,rt,ng", SHAPES)
-def test_default_path_in_the_window_matches_the_oracle(shape, rt, ng):
+@pytest.mark.parametrize("shape,rt,p,ng", SHAPES)
+def test_default_path_in_the_window_matches_the_oracle(shape, rt, p, ng):
     """fixed work (6 outers, CG to 1e-11): k-history 1e-9, flux 1e-8, currents 1e-7 against the oracle; the kernel did run; a second solver
     gives the same bits"""
     inp = synthetic_inputs(*shape, ng=ng, seed=23)
     tol = (0.0, 1e-11, 1e-11, 6, 5000)
-    o = make_oracle(inp, rt, 0); o.set_tol(*tol); o.SolveKeff(); ho = o.history()
+    o = make_oracle(inp, rt, p); o.set_tol(*tol); o.SolveKeff(); ho = o.history()
     runs = []
     for _ in range(2):
-        s = make_hip(inp, rt, 0); s.set_tol(*tol)
+        s = make_hip(inp, rt, p); s.set_tol(*tol)
         k, n = s.solve_keff()
         assert s.info("last_path") == 3 and s.info("xcd_solves") == 6 * ng and s.info("xcd_refused") == 0     # k_keff_xcd: the whole power iteration
         runs.append((k, s.get_phi().copy(), s.history()["k"].copy(), s.get_J().copy(), s.history()["cg"].copy()))
