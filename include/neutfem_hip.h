@@ -192,8 +192,8 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   most "cg_lean_max_cells" cells (default 4 Mi; "cg_lean_grid" = blocks of the residual update), no k_cg_logic launches on slab teams;
  *   "cg_fuse3" (default 1) runs the x, y and z passes of an apply as ONE launch (two launches per CG iteration) on undivided meshes of
  *   at most "cg_fuse3_max_cells" cells (default 400 000: above, the four-launch lean iteration is faster);
- *   "cg_xcd" (default 1) runs every CG solve of an undivided mesh with one unknown per cell and "cg_xcd_min_cells" .. "cg_xcd_max_cells"
- *   cells (default 2000 .. 28000) as ONE launch on the workgroups of XCD "cg_xcd_id" (default 0; 8..15 name none: the solve falls back,
+ *   "cg_xcd" (default 1) runs every CG solve of an undivided mesh (any order, x lines of at most 128 cells) with "cg_xcd_min_cells" ..
+ *   "cg_xcd_max_cells" unknowns per group (default 2000 .. 28000) as ONE launch on the workgroups of XCD "cg_xcd_id" (default 0; 8..15 name none: the solve falls back,
  *   for tests), "cg_xcd_groups" (default 32) workgroups per XCD being launched; nf_info "xcd_solves" counts its solves, "xcd_refused"
  *   the times its workgroups did not assemble and the launch path took over; "keff_xcd" (default 1) runs the whole SolveKeff of such a mesh
  *   (iterative full-Schur path, no CMFD) in one launch of the same kind (nf_info "last_path" 3);
