@@ -1,3 +1,3 @@
 #!/bin/bash
 OUT=gpurun_out/r03_x; mkdir -p $OUT
-timeout -k 10 500 python -m pytest tests/test_gpu_xcd.py -x -q -m gpu > $OUT/pytest_xcd.txt 2>&1; rc=$?; tail -25 $OUT/pytest_xcd.txt; echo "xcd tests rc=$rc"
+timeout -k 10 300 python profiles/tools/xcd_stress.py 150 1 iaea2d 1 > $OUT/xcd_stress_rt1.txt 2>&1; rc=$?; tail -4 $OUT/xcd_stress_rt1.txt; echo "rc=$rc"

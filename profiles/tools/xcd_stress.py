@@ -1,7 +1,7 @@
 """k_keff_xcd under uneven load: repeated IAEA-3D 38x38x19 solves (coarse start, drivers' settings) while ANOTHER process streams the 256^3
 benchmark through every compute unit of the same GPU.  Every solve must give the bits of the first one (fixed summation order), or --
 when the workgroups did not assemble in time and the launch path took over (xcd_refused) -- the launch path's bits.
-usage: xcd_stress.py [solves] [whole = 1]"""
+usage: xcd_stress.py [solves] [whole = 1] [case = iaea3d] [rt = 0]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,11 +9,12 @@ import numpy as np
 from helpers import TEST_TOL, load_inputs, make_hip
 n_solves = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 whole = int(sys.argv[2]) if len(sys.argv) > 2 else 1                # 1: k_keff_xcd (whole SolveKeff), 0: k_cg_xcd under the host's outer loop
-inp = load_inputs("iaea3d"); f = [int(v) for v in inp["coarse_factors"]]
+case = sys.argv[3] if len(sys.argv) > 3 else "iaea3d"; rt = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+inp = load_inputs(case); f = [int(v) for v in inp["coarse_factors"]]
 
 
 def solve(xcd):
-    s = make_hip(inp); s.set_tol(*TEST_TOL); s.set_option("cg_xcd", xcd); s.set_option("keff_xcd", whole)
+    s = make_hip(inp, rt, rt); s.set_tol(*TEST_TOL); s.set_option("cg_xcd", xcd); s.set_option("keff_xcd", whole)
     k, n = s.solve_keff(True, f)
     out = (k, n, s.get_phi().copy(), s.info("xcd_refused"), s.info("last_path"))
     s.close()
