@@ -2699,7 +2699,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             T->last_path = 0; T->profile = prof_req;              // the device refused the LDS the resident kernel plans with: host-driven path
         }
     }
-    // mid-size meshes with one unknown per cell: the whole power iteration in one launch on one XCD (k_keff_xcd)
+    // mid-size meshes (2 k - 28 k unknowns per group, every order): the whole power iteration in one launch on one XCD (k_keff_xcd)
     if (single && !use_diag && !use_cmfd && !direct && !dense && !T->rccl_reduce && o->max_outer > 0 && T->opt_keffx && T->opt_fuse && T->opt_lean && T->opt_fuse3 &&
         S0->N <= T->fuse3_max_cells && S0->N <= T->lean_max_cells) {
         const Fuse3Plan f3 = fuse3_plan(S0);

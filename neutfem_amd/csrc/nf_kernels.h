@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// A whole CG solve (src/solvers.cpp:577-636) of a mid-size undivided RT0-P0 mesh in ONE launch, on the workgroups of ONE XCD.
+// A whole CG solve (src/solvers.cpp:577-636) of a mid-size undivided mesh (any order) in ONE launch, on the workgroups of ONE XCD.
 // Between the one-workgroup resident kernel (a few thousand unknowns) and the meshes that fill the chip, a CG iteration is two
 // dependent launches (k_apply3, k_cg_rupdate3) whose cost is the launch boundary itself: 7.2 + 4.3 us of kernels that mostly wait for
 // their first loads (L2 was written back at the boundary) plus 3.7 us of gap, on IAEA-3D 38x38x19.  The two reductions of an
@@ -1523,9 +1523,9 @@ __global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, con
 //     uniform across workgroups without flags, and no scalar lives in memory during the solve.
 // Phase A of an iteration = what k_apply3 does (q_x = C p + X p with the deferred x_sol += alpha p, p' = r + beta p written to the
 // other buffer of the pair; q_y = Y p, q_z = Z p from p formed on the fly; p.q partials), phase B = k_cg_rupdate3.  Inside a
-// 1024-thread workgroup the three roles run side by side on different wavefronts (x: one wave-task per wave; y / z: sub-tiles of
+// 768-thread workgroup (XCD_THREADS) the three roles run side by side on different wavefronts (x: one wave-task per wave; y / z: sub-tiles of
 // TX NSEG threads packed into the role's waves; the x waves keep the two barriers of a tile company).
-// Partial sums: one per workgroup, added in workgroup order -- not the order of the launch path, so the iterates differ from it in
+// Partial sums: one per workgroup, added by wave_sum's fixed tree over the workgroups -- not the order of the launch path, so the iterates differ from it in
 // the last bits (like the resident kernel's do); every run gives the same bits.
 struct ResidentOut { double keff; int n_outer, status, cg_total, pad; };   // status 0 ok, 2 diverged (non-finite k or dphi); k_keff_xcd: 3 not assembled, 4 barrier timeout
 struct XcdState { unsigned arrived, nreg, count, timeout; };

@@ -5,7 +5,7 @@
 #   3. --pmc WRITE_SIZE (own pass)    -> HBM write traffic per dispatch
 # then profiles/summarize.py condenses the CSVs into profiles/<tag>_kernel_stats.csv and <tag>_pmc_traffic.json.
 set -e
-TAG=${1:-r03_zzz}
+TAG=${1:-r03_zzzz}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 ARGS="--steps 2 --warmup 1 --cpu-sample-iters 0 --no-converge --no-parity --no-small --no-c5"

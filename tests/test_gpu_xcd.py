@@ -1,4 +1,4 @@
-"""k_cg_xcd / k_keff_xcd: the whole CG solve (src/solvers.cpp:577-636) of a mid-size mesh with one unknown per cell in ONE launch on the workgroups of one
+"""k_cg_xcd / k_keff_xcd: the whole CG solve (src/solvers.cpp:577-636) of a mid-size mesh in ONE launch on the workgroups of one
 XCD.  It is the default between 2 000 and 28 000 unknowns per group (every order); these tests run it there, with default options, against the
 oracle -- tests/test_gpu_paths.py forces it onto the small shapes of the path matrix as well."""
 import numpy as np
