@@ -169,9 +169,43 @@ def note(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N fresh ranks the way the driver does (python -m torch.distributed.run,
+    one process per GPU) and hand back their exit code.  This parent never touches the GPU -- no HIP call, no library load --: it relays
+    the children's output (rank 0's one JSON line on stdout) and exits with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    argv, skip = [], False
+    for tok in sys.argv[1:]:                                     # torch.distributed.run's own parser takes `--n` for `--nnodes`: the mesh size travels in the environment
+        if skip:
+            skip = False
+        elif tok == "--n":
+            skip = True
+        elif not tok.startswith("--n="):
+            argv.append(tok)
+    env = dict(os.environ, NEUTFEM_BENCH_N=str(a.n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print(f"[bench] --gpus {a.gpus} without a launcher environment: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    # the rank count is what --gpus says, and the launcher must agree: a run that quietly used another number of ranks would print a
+    # well-formed line for the wrong N
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to run (start it as `python bench.py --gpus {a.gpus}` "
+              f"or `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}`)", file=sys.stderr, flush=True)
+        raise SystemExit(2)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = int(os.environ.get("NEUTFEM_FORCE_DEVICE", local))   # tests: several ranks on the one GPU of the box (tests/test_gpu_multiproc.py)
     from neutfem_amd import capi, cases                       # loads libneutfem_hip.so (and with it the ROCm HIP runtime) first
@@ -210,6 +244,9 @@ def main():
                 idt = torch.frombuffer(bytearray(capi.HipTeam.unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(idt, 0)
             s.comm_init(bytes(idt.numpy().tobytes()), world, rank)
+        comm_ranks, transport = s.comm_info()
+        if world > 1 and comm_ranks not in (world, -1):
+            raise SystemExit(f"bench.py: rank {rank}: the communicator counts {comm_ranks} ranks, the launcher {world}")
         head = s.head
         N_local = sum(x.ne for x in s.slabs); ng, dim = head.ng, head.dim
         N = a.n * a.n * nz
@@ -220,6 +257,7 @@ def main():
         s = make_solver(case, local)
         note("built")
         head = s
+        comm_ranks, transport = 0, ""
         N, ng, dim = s.ne, s.ng, s.dim
     TOL_FLUX, MAX_INNER = a.cg_tol, (1000 if a.cg_tol >= 1e-4 else 20000)   # drivers: set_tol(1e-5,1e-4,1e-4,200,1000)
     if a.case == "checker":                                     # fixed work, exactly 50 CG iterations per group solve
@@ -337,7 +375,8 @@ def main():
         roofline["measured_copy"].update(hbm_traffic_GBps=round(tg, 1), hbm_traffic_frac_of_copy=round(tg / copy_gbs, 4))
 
     out = dict(metric="outer power-iters/sec (IAEA-3D RT0-P0 k-eigenvalue solve)" if a.case == "iaea3d" else "outer power-iters/sec (synthetic checkerboard RT0-P0 k-eigenvalue solve, fixed work)", value=round(a.steps / dt, 4), unit="outer-iters/s",
-               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
+               n_gpus=world, rccl_ranks=(comm_ranks if world > 1 else 1), transport=(transport if world > 1 else "none (one rank: no collective on the data path)"),
+               steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=(f"IAEA-3D resampled {a.n}x{a.n}x{nz} RT0-P0 2g" if a.case == "iaea3d" else case["name"]) +
                            (f", full Schur path, CG tol {a.cg_tol:g}, Chebyshev" if a.case == "iaea3d" else ", full Schur path, exactly 50 CG iterations per group solve, Chebyshev"),

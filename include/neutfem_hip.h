@@ -61,6 +61,9 @@ int nf_create_slab(int rt_order, int p_order, int ng,
 int nf_link_slabs(nf_handle *handles, int n);
 int nf_comm_unique_id(void *id128_host);
 int nf_comm_init(nf_handle h, const void *id128_host, int nranks, int rank);
+/* what carries the data path: *comm_ranks = ncclCommCount of the live communicator (0: none, -1: the library lacks the entry),
+ * lib_path = file the RCCL symbols were resolved from ("" without a communicator).  bench.py prints both (rccl_ranks, transport). */
+int nf_comm_info(nf_handle h, int *comm_ranks, char *lib_path_host, size_t len);
 /* diagnostic: grouped ncclSend/ncclRecv to the own rank on the comm stream + all-reduce(max) through the loaded RCCL */
 int nf_comm_selftest(nf_handle h);
 /* Schur apply on every local slab: x_dev[i] / y_dev[i] = device vectors of local slab i */

@@ -12,7 +12,7 @@ from . import lib_path
 
 SYMBOLS = [
     "nf_last_error", "nf_device_count", "nf_create", "nf_destroy", "nf_create_slab", "nf_link_slabs", "nf_comm_unique_id",
-    "nf_comm_init", "nf_comm_selftest", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
+    "nf_comm_init", "nf_comm_info", "nf_comm_selftest", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_coarsen", "nf_prolong", "nf_timers", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
     "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy", "nf_progress", "nf_local_matrices",
@@ -47,6 +47,7 @@ def load():
     L.nf_link_slabs.argtypes = [C.POINTER(vp), C.c_int]
     L.nf_comm_unique_id.argtypes = [vp]
     L.nf_comm_selftest.argtypes = [vp]
+    L.nf_comm_info.argtypes = [vp, ip, C.c_char_p, C.c_size_t]
     L.nf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.nf_team_schur_apply.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.nf_info.restype = C.c_long
@@ -349,6 +350,12 @@ class HipTeam:
             s.close()
 
     def comm_selftest(self): self.head._chk(self.L.nf_comm_selftest(self.head.h))
+
+    def comm_info(self):
+        """(ranks of the live communicator as the transport library counts them, path of the library that carries the data)"""
+        n = C.c_int(); buf = C.create_string_buffer(512)
+        self.head._chk(self.L.nf_comm_info(self.head.h, C.byref(n), buf, 512))
+        return n.value, buf.value.decode()
 
     def comm_init(self, id_bytes, nranks, rank):
         buf = C.create_string_buffer(bytes(id_bytes), 128)

@@ -72,6 +72,8 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*CommAbort)(ncclComm_t) = nullptr;          // optional: used when a peer stops answering (comm_timeout_s)
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;   // optional: nf_comm_info reports what the LIVE communicator says, not what the launcher claimed
+    char path[512] = { 0 };                          // file the symbols were actually resolved from (dladdr)
 };
 static Rccl g_rccl;
 // NEUTFEM_TRACE_COMM=1: one line on stderr per collective this rank issues (debugging the order of collectives across ranks)
@@ -95,6 +97,9 @@ static int rccl_load()
     SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     *(void **)(&g_rccl.CommAbort) = dlsym(g_rccl.lib, "ncclCommAbort");
+    *(void **)(&g_rccl.CommCount) = dlsym(g_rccl.lib, "ncclCommCount");
+    Dl_info di;
+    if (dladdr((void *)g_rccl.AllReduce, &di) && di.dli_fname) snprintf(g_rccl.path, sizeof g_rccl.path, "%s", di.dli_fname);
     return NF_OK;
 }
 
@@ -566,6 +571,20 @@ int nf_comm_init(nf_handle S, const void *id128, int nranks, int rank)
     ncclUniqueId id; memcpy(&id, id128, sizeof id);
     NCCLCHK(g_rccl.CommInitRank(&T->comm, nranks, id, rank));
     T->nproc = nranks; T->rank = rank; T->linked_ready = false; T->rccl_reduce = true;
+    return NF_OK;
+}
+
+// What carries the data path of this team: ranks of the live communicator as the library itself counts them (ncclCommCount; 0 = no
+// communicator, -1 = the library has no such entry) and the file the RCCL symbols were resolved from.
+int nf_comm_info(nf_handle S, int *comm_ranks, char *lib_path, size_t len)
+{
+    if (!S) return fail(NF_ERR_ARG, "null handle");
+    nf_team *T = S->team;
+    if (comm_ranks) {
+        *comm_ranks = 0;
+        if (T->comm) { *comm_ranks = -1; int n = 0; if (g_rccl.CommCount && g_rccl.CommCount(T->comm, &n) == 0) *comm_ranks = n; }
+    }
+    if (lib_path && len) snprintf(lib_path, len, "%s", T->comm ? g_rccl.path : "");
     return NF_OK;
 }
 

@@ -1,4 +1,4 @@
-// fake_rccl.cpp -- TEST INFRASTRUCTURE: a host-staged stand-in for the nine RCCL entry points libneutfem_hip.so uses,
+// fake_rccl.cpp -- TEST INFRASTRUCTURE: a host-staged stand-in for the ten RCCL entry points libneutfem_hip.so uses,
 // so that the real multi-process code path (nf_comm_init, interface planes between ranks, scalar all-reduces, bench.py
 // --gpus N) can run with several processes on the ONE GPU of a test box -- RCCL itself refuses two ranks on one device.
 // Selected with NEUTFEM_RCCL_LIB=<this .so>; never loaded otherwise.
@@ -133,6 +133,7 @@ int ncclCommDestroy(ncclComm_t c)
     delete c;
     return 0;
 }
+int ncclCommCount(const ncclComm_t c, int *n) { if (!c || !n) return 1; *n = c->nranks; return 0; }
 int ncclGroupStart() { return 0; }
 int ncclGroupEnd() { return 0; }
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t st)

@@ -37,3 +37,33 @@ def test_watchdog_ends_a_rank_whose_solve_makes_no_progress():
 def test_watchdog_leaves_a_progressing_solve_alone():
     r = _run(True)
     assert r.returncode == 0 and "survived" in r.stdout
+
+
+def _bench(args, env_extra):
+    e = dict(os.environ); e.update(env_extra)
+    for k in ("RANK", "LOCAL_RANK") + (() if "WORLD_SIZE" in env_extra else ("WORLD_SIZE",)):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300, cwd=ROOT)
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """--gpus N is binding: under a launcher that started another number of ranks bench.py exits non-zero before it touches anything
+    (it used to run WORLD_SIZE ranks and print their count with rc 0)"""
+    r = _bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode == 2 and "--gpus 2 but the launcher started WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+    r = _bench(["--gpus", "8"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    assert _bench(["--gpus", "0"], {}).returncode != 0
+
+
+def test_bench_starts_its_own_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks through torch.distributed.run and hands back their
+    exit code; here (no GPU) the ranks end with the loud no-device error and the parent with a non-zero code -- never a line for n_gpus 1.
+    On the GPU box the same form runs to its JSON line (tests/test_gpu_multiproc.py::test_bench_two_ranks_on_one_gpu)."""
+    import pytest
+    from neutfem_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("CPU-side check; the GPU suite runs the same command to completion")
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "32"], {})
+    assert r.returncode != 0 and "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert "no HIP device visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -156,23 +156,28 @@ def test_failing_rank_stops_every_rank_instead_of_hanging_them(tmp_path, route, 
 
 
 def test_bench_two_ranks_on_one_gpu():
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo rendezvous, RCCL id broadcast, slab
-    split, barrier + max-over-ranks timing, one JSON line from rank 0) -- both ranks forced onto device 0"""
+    """`python bench.py --gpus 2` as a user (or the driver at N = 1's form) types it: bench.py itself starts the two ranks the way the
+    driver does for N = 2 (python -m torch.distributed.run, gloo rendezvous, RCCL id broadcast, slab split, barrier + max-over-ranks
+    timing, one JSON line from rank 0) -- both ranks forced onto device 0 -- and the line says how many ranks the live communicator
+    counts and which library carried the data (--gpus used to be ignored)"""
     e = _env(); e["NEUTFEM_FORCE_DEVICE"] = "0"; e["NEUTFEM_BENCH_N"] = "64"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
-    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"): e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=e, capture_output=True, text=True, timeout=400, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "starting 2 ranks" in r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                       # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["transport"].endswith("libfake_rccl.so"), (d["n_gpus"], d["rccl_ranks"], d["transport"])
+    assert d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     # same workload on one rank: the power iteration is the same algorithm, k after the timed steps must agree
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample-iters", "0",
                          "--no-converge", "--no-parity", "--no-small"], env=e, capture_output=True, text=True, timeout=400, cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["rccl_ranks"] == 1
     assert abs(d["keff_after_timed_steps"] - d1["keff_after_timed_steps"]) / d1["keff_after_timed_steps"] < 1e-6
 
 
