@@ -116,6 +116,11 @@ struct nf_team {
     hipEvent_t ev_z1 = nullptr, ev_xchg = nullptr;
     int nproc = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    // option "xchg_comm": the interface planes travel on a communicator of their own (created collectively in team_prepare), so that the
+    // first contact with RCCL on several GPUs can A/B "one communicator driven from two streams" against "one communicator per stream"
+    ncclComm_t comm_x = nullptr; int opt_xchg_comm = 0;
+    // single-reduction CG on slab teams (Cg1 in nf_kernels.h): one all-reduce per CG iteration instead of two
+    int opt_cg1 = 1, last_cg_reductions = 0;
     bool rccl_reduce = false;       // scalar reductions go through ncclAllReduce (nproc > 1, or forced for testing)
     double *d_partials = nullptr; long partial_stride = 0, slab_cap = 0;
     CgScalars *d_cg = nullptr;
@@ -222,6 +227,7 @@ struct nf_solver {
     CgFuse fuse = { nullptr, nullptr, nullptr };        // set by cg_solve around the applies of a fused CG (k_schur_x / k_schur_s mode 1)
     CgLean lean = { nullptr, nullptr, 0, 0, 0 };        // set by cg_solve per iteration of a lean CG (k_schur_x consumes the |r|^2 partials)
     CgLean lean_z1 = { nullptr, nullptr, 0, 0, 0 };     // slab teams: the endpoint pass of the z lines consumes the all-reduced |r|^2
+    Cg1 cg1 = { nullptr, nullptr, 0 };                  // slab teams, single-reduction CG (set by cg_solve per iteration): the z passes take their SR instantiations
     bool zw_dot = false;                                // this apply: the y / z passes emit T_a sum z_f w_f as their share of x.y (team_schur_apply, split)
     hipStream_t pass_stream = nullptr;                  // this launch goes to another stream than the team's (x || y on small slabs)
     bool pass_noacc = false; const double *pass_yadd = nullptr;   // SlabArgs::noacc / yadd of this launch
@@ -370,6 +376,7 @@ static void team_free(nf_team *T)
     if (T->stream) (void)hipStreamSynchronize(T->stream);
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (T->comm_x && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm_x);
     if (T->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(T->comm);
     if (T->d_xcd) (void)hipFree(T->d_xcd);
     dfree(T->d_xpart);
@@ -643,7 +650,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("rt_order", S->k); K("p_order", S->m); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce); K("last_xcd", T->last_xcd); K("xcd_solves", T->xcd_solves); K("xcd_refused", T->xcd_refused);
+    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce); K("cg_reductions", T->last_cg_reductions); K("xchg_comm", T->comm_x ? 1 : 0); K("last_xcd", T->last_xcd); K("xcd_solves", T->xcd_solves); K("xcd_refused", T->xcd_refused);
 #undef K
     return -1;
 }
@@ -795,6 +802,7 @@ static int team_stream_wait(nf_team *T, hipStream_t st)
         if (q != hipErrorNotReady) { HIPCHK(q); }
         if (i > 2000) usleep(i > 20000 ? 200 : 20);
         if ((i & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > T->comm_timeout_s) {
+            if (g_rccl.CommAbort && T->comm_x) { (void)g_rccl.CommAbort(T->comm_x); T->comm_x = nullptr; }
             if (g_rccl.CommAbort && T->comm) { (void)g_rccl.CommAbort(T->comm); T->comm = nullptr; }
             return fail(NF_ERR_COMM, "rank %d: a collective did not complete within %.0f s (NEUTFEM_COMM_TIMEOUT_S): a peer rank is gone or stuck", T->rank, T->comm_timeout_s);
         }
@@ -889,14 +897,15 @@ static int exchange_planes(nf_team *T, int which, int g, hipStream_t st)
     if (T->nproc > 1 && (bot->if_lo || top->if_hi)) {
         const size_t cnt = (size_t)bot->nlines[2] * (which == 1 ? 1 : n_modes(bot));
         TRACE_COMM("rank %d exchange which=%d count=%zu lo=%d hi=%d poisoned=%d", T->rank, which, cnt, bot->if_lo, top->if_hi, (int)T->poisoned);
+        ncclComm_t cx = T->comm_x ? T->comm_x : T->comm;
         NCCLCHK(g_rccl.GroupStart());
         if (bot->if_lo) {
-            NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
-            NCCLCHK(g_rccl.Recv(recv_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, T->comm, st));
+            NCCLCHK(g_rccl.Send(send_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, cx, st));
+            NCCLCHK(g_rccl.Recv(recv_lo(bot), cnt, NCCL_DOUBLE, T->rank - 1, cx, st));
         }
         if (top->if_hi) {
-            NCCLCHK(g_rccl.Send(send_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
-            NCCLCHK(g_rccl.Recv(recv_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, T->comm, st));
+            NCCLCHK(g_rccl.Send(send_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, cx, st));
+            NCCLCHK(g_rccl.Recv(recv_hi(top), cnt, NCCL_DOUBLE, T->rank + 1, cx, st));
         }
         NCCLCHK(g_rccl.GroupEnd());
     } else if (bot->if_lo || top->if_hi) {
@@ -911,6 +920,21 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
 static int team_prepare(nf_team *T)
 {
     if (T->linked_ready) return NF_OK;
+    if (T->opt_xchg_comm && T->nproc > 1 && T->comm && !T->comm_x) {
+        // collective: rank 0 draws a second unique id and hands it to the others through the first communicator (an all-reduce(sum) of
+        // its 128 bytes as doubles, zeros from everyone else)
+        ncclUniqueId id2; memset(&id2, 0, sizeof id2);
+        double v[128]; for (double &x : v) x = 0.0;
+        if (T->rank == 0) { NCCLCHK(g_rccl.GetUniqueId(&id2)); for (int i = 0; i < 128; ++i) v[i] = (double)(unsigned char)id2.internal[i]; }
+        DevTmp<double> d; NFCHK(dalloc(&d.p, 128));
+        HIPCHK(hipMemcpyAsync(d.p, v, sizeof v, hipMemcpyHostToDevice, T->stream));
+        NCCLCHK(g_rccl.AllReduce(d.p, d.p, 128, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
+        HIPCHK(hipMemcpyAsync(v, d.p, sizeof v, hipMemcpyDeviceToHost, T->stream));
+        NFCHK(team_stream_wait(T, T->stream));
+        for (int i = 0; i < 128; ++i) id2.internal[i] = (char)(unsigned char)v[i];
+        NCCLCHK(g_rccl.CommInitRank(&T->comm_x, T->nproc, id2, T->rank));
+        TRACE_COMM("rank %d: second communicator for the plane exchange", T->rank);
+    }
     bool any = false;
     for (auto *S : T->slabs) { if (!S->built) return fail(NF_ERR_STATE, "every slab must be built (nf_build) before solving"); any |= S->if_lo || S->if_hi; }
     if (any) {
@@ -1014,6 +1038,16 @@ static int team_reduce(nf_team *T, const std::vector<int> &counts, double *red)
     // red[0] = the sum, red[1] = this rank's error flag: both travel in the one all-reduce (the consumers read red[1], CgLean count < 0)
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, (int)FIN_SUM, T->d_partials, ps, T->partial_stride, 1, T->d_cg, red, 0.0, 0, 1, red, (const double *)T->d_errsrc);
     if (T->rccl_reduce) { TRACE_COMM("rank %d allreduce reduce count=2 poisoned=%d", T->rank, (int)T->poisoned); NCCLCHK(g_rccl.AllReduce(red, red, 2, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream)); }
+    return NF_OK;
+}
+
+// single-reduction CG: the four rows of block partials (p.q, q.q, r.q from the accumulation pass, |r|^2 from the endpoint pass; the same
+// count per slab in every row) -> red[0..3], this rank's error flag -> red[4], one all-reduce of five doubles
+static int team_reduce_sr(nf_team *T, const std::vector<int> &counts)
+{
+    PartSegs ps = segs_for(T, counts);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(256), 0, T->stream, (const double *)T->d_partials, ps, T->partial_stride, T->d_red, (const double *)T->d_errsrc);
+    if (T->rccl_reduce) { TRACE_COMM("rank %d allreduce single-reduction count=5 poisoned=%d", T->rank, (int)T->poisoned); NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 5, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream)); }
     return NF_OK;
 }
 
@@ -1168,7 +1202,18 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     const bool nt = zmode == 0 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;
     const bool nts = zmode != 0 && zmode != 3 && S->nb == 0 && SEG == 8 && T->opt_nt_loads && S->N > T->nt_min_cells;   // the same for the z passes of a slab
     const bool zw = zmode == 0 && S->nb == 0 && S->zw_dot && last && partials;                                              // z.w form of the pass's share of x.y
-#define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+    // single-reduction CG (Cg1): the endpoint pass (mode 1) consumes the reduction of the previous iteration and carries r -= alpha q, the
+    // accumulation pass (mode 2) leaves p.q, q.q, r.q; |r|^2 comes from the endpoint pass (row 3 of the partial buffer)
+    const bool sr = S->cg1.red != nullptr && S->nb == 0 && SEG == 8 && d == 2 && ((zmode == 1 && fz.p) || (zmode == 2 && last && partials));
+    if (sr) {
+        sa.sr = S->cg1; sa.sr_r = S->d_r; sa.sr_q = S->d_q; sa.sr_stride = T->partial_stride;
+        sa.sr_part = T->d_partials + 3 * T->partial_stride + (long)S->slab_index * T->slab_cap;
+    }
+#define NF_S(SEGV, DIRV, SLABV, NBV) do { if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && sr && zmode == 1 && nts) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && sr && zmode == 1) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0, false, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && sr && nts) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && sr) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false, false, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
+        else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (SLABV && NBV == 0 && SEGV == 8 && DIRV == 2 && nts) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, false, SLABV && NBV == 0 && SEGV == 8 && DIRV == 2>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (SLABV && NBV == 0 && fz.p) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
         else if (!SLABV && NBV == 0 && zw && SEGV == 8 && nt) hipLaunchKernelGGL((k_schur_s<SEGV, DIRV, SLABV, NBV, !SLABV && NBV == 0 && SEGV == 8, false, !SLABV && NBV == 0>), grid, block, lds, st, ma, mt, G, L, DR, D0, n, sl, ostride, S->nx, TX, NSEG, last, partials, cg, sa, fz, lz); \
@@ -1527,6 +1572,10 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     // lean variant for slab teams (fused, RT0-P0): the endpoint pass of the z lines and k_cg_rupdate consume the all-reduced
     // totals (d_red[2] = |r|^2, d_red[0] = p.q, each followed by the ranks' error flags) and derive beta / alpha and the stop tests themselves: no k_cg_logic launches
     const bool tlean = fused && T->opt_lean && !team_is_single(T);
+    // single-reduction variant of it (Cg1): one reduction per iteration; needs the 8-cell-segment z passes on every local slab
+    bool sr = tlean && T->opt_cg1 != 0;
+    for (auto *S : T->slabs) sr = sr && S->dim == 3 && S->nb == 0 && (T->opt_s_seg == 0 || T->opt_s_seg == 8) && S->nz <= 1024;
+    T->last_cg_reductions = team_is_single(T) ? 0 : (sr ? 1 : 2);
     // fused-direction variant on top of the lean one (small / medium meshes): two launches per iteration, see k_apply3
     Fuse3Plan f3;
     nf_solver *S0 = T->slabs[0];
@@ -1572,7 +1621,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     const bool multi = T->nproc > 1;
     bool any_if = false; for (auto *S : T->slabs) any_if |= S->if_lo || S->if_hi;
     // vector reduce (see nf_team::d_vec): row 0 of the partial buffer = this rank's p.q partials + flag slot, row 1 = |r|^2 partials + flag slot
-    const bool vred = tlean && multi && ns == 1 && T->vec_ok && T->opt_vec_reduce;
+    const bool vred = tlean && !sr && multi && ns == 1 && T->vec_ok && T->opt_vec_reduce;
     double *send_pq = T->d_partials, *send_rr = T->d_partials + T->partial_stride;
     double *vec_pq = T->d_vec, *vec_rr = vred ? T->d_vec + T->vec_stride : nullptr;
     T->last_vec_reduce = vred ? 1 : 0;
@@ -1616,7 +1665,8 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 continue;
             }
             if (lean) T->slabs[0]->lean = CgLean{ T->d_cg, row1, gru, index & 1, index == 0 ? 1 : 0 };
-            if (tlean) for (auto *S : T->slabs) S->lean_z1 = vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, index & 1, index == 0 ? 1 : 0, T->vec_cnt_rr }
+            if (sr) for (auto *S : T->slabs) S->cg1 = Cg1{ T->d_red, T->d_cg, index };
+            else if (tlean) for (auto *S : T->slabs) S->lean_z1 = vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, index & 1, index == 0 ? 1 : 0, T->vec_cnt_rr }
                                                                    : CgLean{ T->d_cg, T->d_red + 2, -1, index & 1, index == 0 ? 1 : 0 };
             T->xchg_in_apply = 0;
             int ra = NF_OK;
@@ -1624,7 +1674,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 { ra = fail(NF_ERR_HIP, "injected failure on rank %d at CG iteration %ld (NEUTFEM_INJECT_FAIL)", T->rank, global_it); TRACE_COMM("rank %d INJECT at %ld", T->rank, global_it); }
             else if (!T->poisoned) ra = team_schur_apply(T, g, ps, qs, true, T->d_cg, &acnt);
             if (lean) T->slabs[0]->lean = no_lean;
-            if (tlean) for (auto *S : T->slabs) S->lean_z1 = no_lean;
+            if (tlean) for (auto *S : T->slabs) { S->lean_z1 = no_lean; S->cg1 = Cg1{ nullptr, nullptr, 0 }; }
             if (bad(ra)) break;
             if (T->poisoned && any_if) {
                 // the interface exchanges this apply still owes its neighbours: one per apply + one per separator sweep (team_endpoint_phase)
@@ -1636,6 +1686,10 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
                 for (int k = T->xchg_in_apply; k < 1 + T->sep_sweeps; ++k) (void)exchange_planes(T, k == 0 ? 0 : 2, 0, T->comm_stream);
                 (void)hipEventRecord(T->ev_xchg, T->comm_stream); (void)hipStreamWaitEvent(T->stream, T->ev_xchg, 0);
                 for (int i = 0; i < ns; ++i) acnt[i] = 0;
+            }
+            if (sr) {                                             // the one reduction of this iteration; its consumer is the next endpoint pass
+                if (bad(team_reduce_sr(T, acnt))) break;
+                continue;
             }
             if (vred) {
                 // the partial vectors themselves cross the ranks; their consumers sum them (CgLean with a count and a flag slot)
@@ -1685,7 +1739,8 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
             { const int rw = pub_wait(T, seq, &sc, nullptr, 0); if (rw != NF_OK) { rc = rw; break; } }
         } else {
             if (lean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, CgLean{ T->d_cg, row1, gru, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
-            if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, launched & 1, 0, T->vec_cnt_rr }
+            if (sr) hipLaunchKernelGGL(k_cg1_logic, dim3(1), dim3(64), 0, T->stream, Cg1{ T->d_red, T->d_cg, launched }, (HostPub *)nullptr, 0ULL);
+            else if (tlean) hipLaunchKernelGGL(k_cg_lean_rr, dim3(1), dim3(256), 0, T->stream, vred ? CgLean{ T->d_cg, vec_rr, T->vec_cnt_rr, launched & 1, 0, T->vec_cnt_rr }
                                                                                                  : CgLean{ T->d_cg, T->d_red + 2, -1, launched & 1, 0 }, (HostPub *)nullptr, 0ULL);
             { const int rw = readback(T, T->d_cg, &sc, nullptr, nullptr, 0); if (rw != NF_OK) { rc = rw; break; } }
         }
@@ -2061,7 +2116,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     if (CT) {
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
-        CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
+        CT->opt_cg1 = T->opt_cg1; CT->comm_x = T->comm_x; CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
         CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_cgx = T->opt_cgx; CT->opt_keffx = T->opt_keffx; CT->xcd_min_cells = T->xcd_min_cells; CT->xcd_max_cells = T->xcd_max_cells; CT->xcd_id = T->xcd_id; CT->xcd_groups = T->xcd_groups; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
@@ -2081,7 +2136,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         }
         if (hipStreamSynchronize(CT->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
     }
-    if (CT) { CT->comm = nullptr; CT->nproc = 1; CT->rccl_reduce = false; }   // borrowed for the solve only: never destroyed with the coarse team
+    if (CT) { CT->comm = nullptr; CT->comm_x = nullptr; CT->nproc = 1; CT->rccl_reduce = false; }   // borrowed for the solve only: never destroyed with the coarse team
     if (rc != NF_OK) { coarse_cache_drop(T); return rc; }
     *k_coarse = kc; *done = true;
     return NF_OK;
@@ -3150,6 +3205,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
     else if (!strcmp(key, "vec_reduce")) T->opt_vec_reduce = value != 0;
+    else if (!strcmp(key, "cg_single_reduce")) T->opt_cg1 = value != 0;
+    else if (!strcmp(key, "xchg_comm")) { T->opt_xchg_comm = value != 0; if (T->nproc > 1) T->linked_ready = false; }
     else if (!strcmp(key, "xy_overlap")) T->opt_xy_overlap = value != 0;
     else if (!strcmp(key, "xy_overlap_max_cells")) T->xy_overlap_max_cells = std::max(0L, value);
     else if (!strcmp(key, "split_dot")) T->opt_split_dot = (int)std::max(0L, std::min(2L, value));   // 0 never, 1 where a chunked pass runs, 2 always (big undivided RT0-P0 meshes)

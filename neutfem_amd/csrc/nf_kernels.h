@@ -21,6 +21,14 @@
 #define NF_STAMP(buf, i) do { } while (0)
 #endif
 
+// waves per SIMD the single-reduction variants of the slab z passes are compiled for (A/B builds: profiles/tools/r04_d_call.sh)
+#ifndef NF_SR_Z1_WAVES
+#define NF_SR_Z1_WAVES 3
+#endif
+#ifndef NF_SR_Z2_WAVES
+#define NF_SR_Z2_WAVES 4
+#endif
+
 namespace nf {
 
 // device-resident state of one CG solve (SchurSolver::SolveSchurImplicit, src/solvers.cpp:577-636)
@@ -309,6 +317,78 @@ __global__ __launch_bounds__(256) void k_cg_lean_rr(CgLean lean, HostPub *hp, un
         __threadfence_system();
         __hip_atomic_store(&hp->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-reduction CG on slab teams (RT0-P0): ONE cross-rank reduction per iteration instead of two.
+// The reference recurrence (src/solvers.cpp:577-636) needs p.Sp before it can form r_new and |r_new|^2 before it can form the next p:
+// two dependent reductions.  Here the reduction of iteration j carries
+//     red[0] = p_j.q_j   red[1] = q_j.q_j   red[2] = r_j.q_j   red[3] = |r_j|^2 (MEASURED, of the r the iteration started with)   red[4] = error flags
+// and its consumer -- the first pass of iteration j+1 (the endpoint pass of the z lines, which reads p anyway) -- derives
+//     alpha_j = |r_j|^2 / p.q          |r_{j+1}|^2 = |r_j|^2 - 2 alpha r.q + alpha^2 q.q   (the algebraic identity for |r - alpha q|^2)
+//     beta_j  = |r_{j+1}|^2 / |r_j|^2
+// and applies r -= alpha q, x += alpha p, p = r + beta p in one sweep.  The PREDICTED |r_{j+1}|^2 only feeds beta; the next reduction
+// measures |r_{j+1}|^2 again, so nothing accumulates, and the stop test |r|^2 < tol^2 |b|^2 is taken on MEASURED values (one apply
+// late: the solve that the reference ends after iteration j is ended here by the consumer of reduction j, with the same x_j).
+// r.q is measured, not replaced by p.q: on IAEA-3D (blank assemblies with Sigma = 1e15, cond(S) ~ 1e17, |r|^2 swinging by ten orders
+// of magnitude between consecutive iterations) the variants that lean on conjugacy or on r_new . r = 0 -- Chronopoulos-Gear, or
+// |r_new|^2 = alpha^2 q.q - |r|^2 -- never converge (tests/test_single_reduction_cg.py shows it on the CPU oracle); this one needs
+// the reference's iteration counts to within a few per cent there and identical counts on the well-conditioned benchmarks.
+struct Cg1 { const double *red; CgScalars *st; int index; };   // index = iteration about to start (0: nothing to consume yet)
+__device__ __forceinline__ bool cg1_step(const Cg1 &c, bool writer, double *alpha_out, double *beta_out)
+{
+    CgScalars *st = c.st;
+    const double pq = c.red[0], qq = c.red[1], rq = c.red[2], rr = c.red[3], flag = c.red[4];
+    const int j = c.index - 1;                                   // the iteration these sums belong to
+    *alpha_out = 0.0; *beta_out = 0.0;
+    const int e = flag != 0.0 ? 2 : ((((pq - pq) + (qq - qq)) + ((rq - rq) + (rr - rr))) != 0.0 ? 1 : 0);
+    if (e) { if (writer) { st->err = e; st->done = 1; st->rr = rr; st->its = j; st->pend = 0; } return true; }
+    if (j >= 1 && rr < st->tol_sq) { if (writer) { st->rr = rr; st->rr_new = rr; st->its = j; st->pend = 0; st->done = 1; } return true; }   // :624-628, on the measured |r_j|^2
+    if (fabs(pq) < 1e-30) { if (writer) { st->pAp = pq; st->rr = rr; st->its = j; st->pend = 0; st->done = 1; } return true; }              // :604
+    const double alpha = rr / pq;
+    double rn = fma(alpha, fma(alpha, qq, -2.0 * rq), rr);       // |r - alpha q|^2
+    if (!(rn > 0.0)) rn = 0.0;                                    // cancelled below rounding: restart from the residual (beta = 0)
+    const double beta = rn / rr;
+    const bool stop = j + 1 >= st->maxit;                        // the reference's loop bound: x still owes alpha_j p_j (k_cg_flush, pend)
+    if (writer) {
+        st->pAp = pq; st->alpha = alpha; st->beta = beta; st->its = j + 1; st->rr_new = rn;
+        st->rr = stop ? rn : rr; st->pend = stop ? 1 : 0;
+        if (stop) st->done = 1;
+    }
+    *alpha_out = alpha; *beta_out = beta;
+    return stop;
+}
+// The four rows of block partials of one iteration -> red[0..3] (+ this rank's error flag -> red[4]): one wavefront per row, every lane
+// sums the entries l, l + 64, ... of each slab's segment with eight loads in flight, one cross-lane sum at the end.  No barrier, no
+// serial tail: ~3 us where k_finalize (one row and one segment at a time behind block-wide barriers) took 58 us for 4 x 8 x 256 partials.
+__global__ __launch_bounds__(256) void k_reduce_rows(const double *__restrict__ partials, PartSegs segs, long stride, double *__restrict__ red,
+                                                     const double *__restrict__ errsrc)
+{
+    const int row = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double *p = partials + (long)row * stride;
+    double s = 0.0;
+    for (int sg = 0; sg < segs.n; ++sg) {
+        const double *q = p + segs.off[sg]; const int cnt = segs.cnt[sg];
+        int i = lane;
+        for (; i + 7 * 64 < cnt; i += 8 * 64) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = q[i + j * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; i < cnt; i += 64) s += q[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[row] = s;
+    if (threadIdx.x == 0 && errsrc) red[4] = *errsrc;
+}
+// the consumer's step on its own (end of a batch of iterations: the host is about to read the scalars), idempotent
+__global__ void k_cg1_logic(Cg1 c, HostPub *hp, unsigned long long seq)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!c.st->done && c.index > 0) { double a, b; (void)cg1_step(c, true, &a, &b); }
+    if (hp) { hp->cg = *c.st; __threadfence_system(); __hip_atomic_store(&hp->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -849,6 +929,9 @@ struct SlabArgs {
     double *jz;                               // mode 3: J = -u on the slab's own z faces [((face) * nx * ny + line) * nfa + amode] (Sol_J_, src/solvers.cpp:228)
     double *jzb;                              // mode 3, RT1+: the z bubbles of the slab's cells [cell * ni + l + k * amode] (src/FEM.cpp:377-397)
     int nfa, ni, amode[9];                    // RT face / interior DOFs per face / cell and direction; RT transverse index of every P mode
+    // single-reduction CG (template flag SR, see Cg1): mode 1 consumes the reduction of the previous iteration and carries r -= alpha q next
+    // to the fused x / p update, leaving its blocks' shares of |r|^2 in sr_part; mode 2 leaves p.q, q.q and r.q in three rows of partials
+    Cg1 sr; double *sr_r; const double *sr_q; double *sr_part; long sr_stride;
 };
 // One tile (TX columns x one line each, NSEG segments) of a y / z pass.  tid = thread index within the tile; threads with
 // act == false only keep the barriers company.  acc: accumulate into y (the x pass ran before) or store the increment alone
@@ -862,13 +945,14 @@ struct SlabArgs {
 // (eight doubles fewer live through the scans, and the chunked long-line pass has nothing to re-read for its parked chunk).
 // XC (k_cg_xcd: the producers of x and r are other workgroups of the SAME launch on the same XCD): every load of x and r bypasses the
 // compute unit's L1 -- the overlap cell too
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid, bool ZW = false, bool XC = false>   // NTS: streaming loads in a slab variant
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, class Mid = NoMid, bool ZW = false, bool XC = false, bool SR = false>   // NTS: streaming loads in a slab variant
 __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G, const double *__restrict__ L, const double *__restrict__ DR,
                                                const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                                                unsigned bx, unsigned by, unsigned bz, unsigned gy, int tid, bool act, double *sm,
                                                const SlabArgs &sa, const CgFuse &fz, bool fuse, bool fro, double f_alpha, double f_beta, bool acc,
-                                               long long *stamp = nullptr, Mid mid = Mid())
+                                               long long *stamp = nullptr, Mid mid = Mid(), double *extra = nullptr)
 {
+    static_assert(!SR || (SLAB && NB == 0), "single-reduction CG: RT0-P0 slab passes");
     constexpr bool NT = SLAB ? NTS : SF;                         // big meshes: streaming loads (ldg); SF doubles as that flag on undivided meshes
     const double *x = ma.x[0];                                   // no __restrict__: the fused slab pass rewrites this vector (fz.p)
     double *__restrict__ y = ma.y[0];
@@ -907,7 +991,8 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             // edge), towards the separator xL / xR -- for RT0 all four are the cell value itself
             if (sa.if_lo) {
                 a_lo = sa.alo[lineid]; x_before = x[edge_lo];
-                if (fuse) { if (seg == 0) fz.xsol[edge_lo] = fma(f_alpha, x_before, fz.xsol[edge_lo]); x_before = fma(f_beta, x_before, fz.r[edge_lo]); }
+                if (fuse) { if (seg == 0) fz.xsol[edge_lo] = fma(f_alpha, x_before, fz.xsol[edge_lo]);
+                            x_before = fma(f_beta, x_before, (SR && SF) ? fma(-f_alpha, sa.sr_q[edge_lo], fz.r[edge_lo]) : fz.r[edge_lo]); }
                 xe_lo = x_before;
                 if (NB > 0) {
                     const double g1 = ma.Gc[0] * ma.x[1][edge_lo], g2 = NB > 1 ? ma.Gc[1] * ma.x[2][edge_lo] : 0.0;
@@ -918,7 +1003,8 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             }
             if (sa.if_hi) {
                 a_hi = sa.ahi[lineid]; x_after = x[edge_hi];
-                if (fuse) { if (seg == 0) fz.xsol[edge_hi] = fma(f_alpha, x_after, fz.xsol[edge_hi]); x_after = fma(f_beta, x_after, fz.r[edge_hi]); }
+                if (fuse) { if (seg == 0) fz.xsol[edge_hi] = fma(f_alpha, x_after, fz.xsol[edge_hi]);
+                            x_after = fma(f_beta, x_after, (SR && SF) ? fma(-f_alpha, sa.sr_q[edge_hi], fz.r[edge_hi]) : fz.r[edge_hi]); }
                 xe_hi = x_after;
                 if (NB > 0) {
                     const double g1 = ma.Gc[0] * ma.x[1][edge_hi], g2 = NB > 1 ? ma.Gc[1] * ma.x[2][edge_hi] : 0.0;
@@ -940,6 +1026,8 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     if (SLAB && !SF) fuse = false;
     const bool fr = SLAB ? fuse : fro;                           // the input vector is r + beta x (wave-uniform)
     double rv[(SLAB && !SF) ? 1 : SEG + 1], sv[(SLAB && SF) ? SEG : 1];   // r of the same cells; slab fuse: x_sol of the owned cells
+    double qv[(SR && SF) ? SEG + 1 : 1], rq_[(SR && !SF) ? SEG : 1];      // SR: q of the same cells (endpoint pass); r of the owned cells (accumulation pass)
+    double srr = 0.0, sqq = 0.0, srq = 0.0;
     double r1[NB > 0 ? SEG + 1 : 1], r2[NB > 1 ? SEG + 1 : 1], v1a[NB > 0 ? SEG + 1 : 1], v2a[NB > 1 ? SEG + 1 : 1], Dv[NB > 0 ? SEG : 1];
 #pragma unroll
     for (int i = 0; i <= SEG; ++i) {
@@ -949,6 +1037,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
         if (i < SEG || XC) xv[i] = ok ? ldg<NT>(x + a) : 0.0; else xv[i] = ok ? x[a] : 0.0;
         if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : ldg<NT>(x + a + roff)) : 0.0;
         if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
+        if (SR && SF) qv[(SR && SF) ? i : 0] = (fuse && ok) ? sa.sr_q[a] : 0.0;
         if (i < SEG) Lv[i] = ok ? ldg<NT>(L + a) : 0.0; else Lv[i] = ok ? L[a] : 0.0;
         if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
         if (NB > 0) {
@@ -968,9 +1057,11 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     for (int i = 0; i <= SEG; ++i) {
         const int c = c0 + i; const bool ok = valid && c < n;
         if ((!SLAB || SF) && fr) {
+            if (SR && SF) rv[(SLAB && !SF) ? 0 : i] = fma(-f_alpha, qv[(SR && SF) ? i : 0], rv[(SLAB && !SF) ? 0 : i]);   // r -= alpha q (src/solvers.cpp:610)
             if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = fma(f_alpha, xv[i], sv[(SLAB && SF) ? i : 0]);   // owned cell; the overlap cell (i == SEG) belongs to the next segment
             xv[i] = fma(f_beta, xv[i], rv[(SLAB && !SF) ? 0 : i]);
         }
+        if (SR && SF && i < SEG) { const double rn = fr ? rv[(SLAB && !SF) ? 0 : i] : xv[i]; srr += ok ? rn * rn : 0.0; }   // |r|^2 of the owned cells (first iteration: p = r)
         if (SLAB && valid && c == n) xv[i] = x_after;
         if (NB > 0) {
             double v1 = v1a[i], v2 = NB > 1 ? v2a[NB > 1 ? i : 0] : 0.0;
@@ -1035,6 +1126,20 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 #pragma unroll
         for (int i = 0; i < SEG; ++i) if (c0 + i < n) fz.p[base + (long)(c0 + i) * sl] = xv[i];
         if (seg == 0) { if (sa.if_lo) fz.p[edge_lo] = xe_lo; if (sa.if_hi) fz.p[edge_hi] = xe_hi; }
+        if (SR && SF) {                                          // the updated residual: other threads of the block read the old one above (overlap and edge cells)
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) if (c0 + i < n) sa.sr_r[base + (long)(c0 + i) * sl] = rv[(SLAB && !SF) ? 0 : i];
+            // edge cells: every thread of the column formed r - alpha q for its p above; the owner (segment 0) forms it once more here,
+            // behind the barrier, rather than keeping it alive across the scans -- the old r and q are still in place, it is their only writer
+            if (seg == 0) {
+                if (sa.if_lo) { const double re = fma(-f_alpha, sa.sr_q[edge_lo], fz.r[edge_lo]); sa.sr_r[edge_lo] = re; srr += re * re; }
+                if (sa.if_hi) { const double re = fma(-f_alpha, sa.sr_q[edge_hi], fz.r[edge_hi]); sa.sr_r[edge_hi] = re; srr += re * re; }
+            }
+        }
+    }
+    if (SR && SF && !fuse && valid && seg == 0) {                // first iteration: r = p, untouched
+        if (sa.if_lo) { const double re = x[edge_lo]; srr += re * re; }
+        if (sa.if_hi) { const double re = x[edge_hi]; srr += re * re; }
     }
     double z;
     if (wscan) z = sB[si];
@@ -1068,6 +1173,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     NF_STAMP(stamp, 6);
     __syncthreads();
     NF_STAMP(stamp, 7);
+    if (SR && !SF) {                                             // r of the owned cells (for r.q): asked for behind the barrier, so that it is not alive across
+#pragma unroll                                                   // the scans (the pass sits at 128 VGPRs = four blocks of 256 threads per CU); it flies during the backward replay
+        for (int i = 0; i < SEG; ++i) rq_[(SR && !SF) ? i : 0] = (valid && c0 + i < n && wr) ? sa.sr_r[base + (long)(c0 + i) * sl] : 0.0;
+    }
     double u = 0.0;
     if (wscan) {
         // backward: incoming value of segment s = (f_{s+1} o ... o f_{NSEG-1})(0) = the B part of the suffix composition at s + 1
@@ -1098,6 +1207,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             const double lo = i == 0 ? ulo : w[i > 0 ? i - 1 : 0];
             const bool in = valid && c0 + i < n;                 // a select, not a branch (slab chains: xv of the cell behind the chain end is the edge cell)
             yo[i] = yo[i] + ma.Ta * (w[i] - lo); if (!ZW) dot += in ? xv[i] * yo[i] : 0.0;
+            if (SR && !SF) { sqq += in ? yo[i] * yo[i] : 0.0; srq += in ? rq_[(SR && !SF) ? i : 0] * yo[i] : 0.0; }
             if (NB > 0) {
                 const double v = ma.Gc[0] * x1[i] * ma.iM[0] * icv[i] - (ma.eL[0] * lo + ma.eR[0] * w[i]);
                 y1o[i] = y1o[i] + ma.Ta * ma.Gc[0] * v; dot += in ? x1[i] * y1o[i] : 0.0;
@@ -1174,6 +1284,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             else {
                 const double u_lo = sa.fold ? (sa.rlo[lm] + sa.clo[lm]) * sa.sinv_lo[lineid] : sa.ulo[lm];
                 const double xe = x[edge_lo]; const double yv = (y[edge_lo] + ((NB == 0 && sa.yadd) ? sa.yadd[edge_lo] : 0.0)) + ma.Ta * (ulo - u_lo); y[edge_lo] = yv; dot += xe * yv;
+                if (SR && !SF) { sqq += yv * yv; srq += sa.sr_r[edge_lo] * yv; }
                 if (NB > 0) {                                    // bubbles of the edge cell: faces (separator, first chain face)
                     const double ice = ma.D[edge_lo] / geom_factor(G, DIR, ix, (int)by, 0);
 #pragma unroll
@@ -1195,6 +1306,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             else {
                 const double u_hi = sa.fold ? (sa.chi[lm] + sa.rhi[lm]) * sa.sinv_hi[lineid] : sa.uhi[lm];
                 const double xe = x[edge_hi]; const double yv = (y[edge_hi] + ((NB == 0 && sa.yadd) ? sa.yadd[edge_hi] : 0.0)) + ma.Ta * (u_hi - ulast); y[edge_hi] = yv; dot += xe * yv;
+                if (SR && !SF) { sqq += yv * yv; srq += sa.sr_r[edge_hi] * yv; }
                 if (NB > 0) {                                    // faces (last chain face, separator)
                     const int fsz = sa.if_lo ? 1 : 0;
                     const double ice = ma.D[edge_hi] / geom_factor(G, DIR, ix, (int)by, fsz + n);
@@ -1209,13 +1321,15 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             }
         }
     }
+    if (SR && SF) return srr;                                    // endpoint pass: this thread's share of |r|^2
+    if (SR && extra) { extra[0] = sqq; extra[1] = srq; }
     return dot;
 }
 
 // Slab variants keep r and x_sol of their cells in registers next to x, L, 1/d (loads first, see schur_s_tile): blocks of at most 512
 // threads, so that the register budget is 256 per thread (the host picks TX accordingly)
-template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, bool ZW = false>
-__global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4)) : 1) void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
+template <int SEG, int DIR, bool SLAB, int NB, bool SF = false, bool NTS = false, bool ZW = false, bool SR = false>
+__global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? (SR ? NF_SR_Z1_WAVES : 3) : (SR ? NF_SR_Z2_WAVES : 4))) : 1) void k_schur_s(ModeArgs ma0, ModeTab mt, Geom G, const double *__restrict__ L, const double *__restrict__ DR,
                           const double *__restrict__ D0, int n, long sl, long outer_stride, int nx, int TX, int NSEG,
                           int last, double *__restrict__ partials, const CgScalars *__restrict__ cg, SlabArgs sa, CgFuse fz, CgLean lean)
 {
@@ -1225,13 +1339,15 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
     // fused CG on slabs: the endpoint pass (mode 1) is the first to read p in an iteration, so it carries the deferred
     // x_sol += alpha p, p = r + beta p (see CgFuse); every cell of the local line is owned by exactly one thread.
     // With lean.st it is also the consumer of the all-reduced |r|^2 (FIN_RR: beta, stop tests), like the x pass of an undivided mesh.
-    bool fuse = SLAB && SF && NB == 0 && sa.mode == 1 && fz.p != nullptr && (lean.st ? !lean.first : cg->its > 0);
-    double f_beta = fuse && !lean.st ? cg->beta : 0.0;
-    if (SLAB && lean.st && !lean.first) {
+    bool fuse = SLAB && SF && NB == 0 && sa.mode == 1 && fz.p != nullptr && (SR ? sa.sr.index > 0 : (lean.st ? !lean.first : cg->its > 0));
+    double f_beta = fuse && !lean.st && !SR ? cg->beta : 0.0;
+    if (SLAB && !SR && lean.st && !lean.first) {
         double *sred_l = sm + 4 * TX * (NSEG + 1) + TX;
         if (lean_rr_step(lean, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0, sred_l, &f_beta)) return;
     }
-    const double f_alpha = fuse ? cg->alpha : 0.0;
+    double f_alpha = fuse && !SR ? cg->alpha : 0.0;
+    // single-reduction CG: every block derives alpha, beta and the stop decision from the same five all-reduced doubles (see Cg1)
+    if (SR && SF && fuse) { if (cg1_step(sa.sr, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0, &f_alpha, &f_beta)) return; }
     // XCD-aware tile order (experiment, sa.xcd): hardware deals consecutive workgroups round-robin to the 8 XCDs; remap so that
     // each XCD works on one contiguous range of tiles
     unsigned bx = blockIdx.x, by = blockIdx.y;
@@ -1240,13 +1356,25 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? 3 : 4
         if (nblk % 8 == 0) { const unsigned nl = (lin % 8) * (nblk / 8) + lin / 8; bx = nl % gridDim.x; by = nl / gridDim.x; }
     }
     static_assert(!ZW || (!SLAB && NB == 0), "the z.w form of the dot product is for plain RT0-P0 lines");
-    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF, NTS, NoMid, ZW>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
-                                                            (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, !(!SLAB && NB == 0 && sa.noacc));
+    double extra[2] = { 0.0, 0.0 };
+    const double dot = schur_s_tile<SEG, DIR, SLAB, NB, SF, NTS, NoMid, ZW, false, SR>(ma, G, L, DR, D0, n, sl, outer_stride, nx, TX, NSEG, bx, by, blockIdx.z, gridDim.y,
+                                                            (int)threadIdx.x, true, sm, sa, fz, fuse, false, f_alpha, f_beta, !(!SLAB && NB == 0 && sa.noacc),
+                                                            nullptr, NoMid(), SR ? extra : nullptr);
     if (SLAB && sa.mode == 3) return;
-    if (last && partials) {
-        double *sred = sm + 4 * TX * (NSEG + 1) + TX;
+    double *sred = sm + 4 * TX * (NSEG + 1) + TX;
+    const long pidx = ((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx;
+    if (SR && SF) {                                              // endpoint pass: |r|^2 of the residual this iteration starts with
         const double s = block_sum(dot, sred);
-        if (threadIdx.x == 0) partials[((long)blockIdx.z * gridDim.y + by) * gridDim.x + bx] = s;
+        if (threadIdx.x == 0) sa.sr_part[pidx] = s;
+        return;
+    }
+    if (last && partials) {
+        const double s = block_sum(dot, sred);
+        if (threadIdx.x == 0) partials[pidx] = s;
+        if (SR) {                                                // accumulation pass: q.q and r.q next to p.q
+            const double s1 = block_sum(extra[0], sred), s2 = block_sum(extra[1], sred);
+            if (threadIdx.x == 0) { partials[pidx + sa.sr_stride] = s1; partials[pidx + 2 * sa.sr_stride] = s2; }
+        }
     }
 }
 

@@ -74,6 +74,8 @@ struct nfo {
     int last_outer, coarse_outer; long last_cg_total;
     double hist_k[MAXHIST], hist_dk[MAXHIST], hist_dphi[MAXHIST];
     double *hist_cg; int last_cg_its; double last_cg_res;
+    /* NOT in the reference (nfo_set_void, see nf_oracle.h): cells cut out of the domain, with a Robin condition on their faces */
+    unsigned char *voidm; double void_inv_alpha;
 };
 
 /* ---- include/FEM.hpp:82-123 ------------------------------------------------ */
@@ -415,8 +417,21 @@ void nfo_destroy(nfo_t *h)
     for (int d = 0; d < 3; ++d) free(h->Ahat[d]);
     free(h->Bhat); free(h->Chat); free(h->hist_cg);
     for (int d = 0; d < 3; ++d) { free(h->Dt[d]); free(h->Dh[d]); }
+    free(h->voidm);
     free(h);
 }
+
+/* NOT in the reference.  Cells with mask != 0 are cut out of the domain: they contribute nothing to A and B, and every face they
+ * share with a kept cell carries the boundary term A(f,f) += I_f * inv_alpha, i.e. J.n = alpha phi there (the reference's own form of
+ * a boundary term, ApplyDirichletToA, with 1/alpha in the place of its 2 D).  Used by tests/test_oracle.py to compute the IAEA-2D
+ * benchmark AS SPECIFIED (vacuum condition J.n = 0.4692 phi on the stepped core boundary) next to the drivers' variant of it
+ * (blank assemblies filled with reflector, "Dirichlet" on the 380 cm box), which explains the drivers' offset from the literature k. */
+void nfo_set_void(nfo_t *h, const unsigned char *mask, double inv_alpha)
+{
+    free(h->voidm); h->voidm = NULL;
+    if (mask) { h->voidm = (unsigned char *)malloc(h->ne); memcpy(h->voidm, mask, h->ne); h->void_inv_alpha = inv_alpha; }
+}
+static int is_void(const nfo_t *h, long e) { return h->voidm && h->voidm[e]; }
 
 long nfo_info(const nfo_t *h, const char *key)
 {
@@ -555,6 +570,7 @@ int nfo_build(nfo_t *h)
         /* AssembleA(g): NeutFEM.cpp:1036-1076, entries |a| <= 1e-14 dropped (:1064) */
         for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
             long e = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix;
+            if (is_void(h, e)) continue;
             double fac[3], detJ; geom_factors(h, ix, iy, iz, fac, &detJ);
             double invD = 1.0 / h->D[g * ne + e];
             const int *ej = h->eJ + e * nJl;
@@ -585,6 +601,23 @@ int nfo_build(nfo_t *h)
                     A[p * w] += boundary_face_integral(h, f, fa) * 2.0 * D;
                 }
             }
+        }
+        if (h->voidm) {                                              /* nfo_set_void: Robin term on kept|void faces, identity on DOFs no kept cell touches */
+            for (int iz = 0; iz < h->nz; ++iz) for (int iy = 0; iy < h->ny; ++iy) for (int ix = 0; ix < h->nx; ++ix) {
+                long e = (long)iz * h->nx * h->ny + (long)iy * h->nx + ix;
+                if (!is_void(h, e)) continue;
+                const int nn[3] = { h->nx, h->ny, h->nz }, ii[3] = { ix, iy, iz }; const long st[3] = { 1, h->nx, (long)h->nx * h->ny };
+                for (int d = 0; d < dim; ++d) for (int up = 0; up < 2; ++up) {
+                    const int has = up ? ii[d] + 1 < nn[d] : ii[d] > 0;
+                    const long en = has ? e + (up ? st[d] : -st[d]) : -1;
+                    if (has && !is_void(h, en)) {
+                        int jx = ix, jy = iy, jz = iz; if (d == 0) jx += up ? 1 : -1; else if (d == 1) jy += up ? 1 : -1; else jz += up ? 1 : -1;
+                        const double fa = face_area(h, jx, jy, jz, d);
+                        for (int f = 0; f < h->nf; ++f) A[(long)h->eJ[e * nJl + d * nper + (up ? h->nf : 0) + f] * w] += boundary_face_integral(h, f, fa) * h->void_inv_alpha;
+                    }
+                }
+            }
+            for (long p = 0; p < nJ; ++p) if (A[p * w] == 0.0) A[p * w] = 1.0;
         }
         h->Aband[g] = A;
         h->band[g] = (double *)malloc(sizeof(double) * nJ * w);
@@ -638,6 +671,7 @@ static void apply_BT(const nfo_t *h, const double *x, double *t)
     const int nJl = h->nJloc, nP = h->nloc; const long ne = h->ne;
     memset(t, 0, sizeof(double) * h->nJ);
     for (long e = 0; e < ne; ++e) {
+        if (is_void(h, e)) continue;
         const int *ej = h->eJ + e * nJl;
         for (int p = 0; p < nP; ++p) {
             double xv = x[e * nP + p];
@@ -650,6 +684,7 @@ static void apply_B_add(const nfo_t *h, const double *u, double *y)
 {
     const int nJl = h->nJloc, nP = h->nloc; const long ne = h->ne;
     for (long e = 0; e < ne; ++e) {
+        if (is_void(h, e)) continue;
         const int *ej = h->eJ + e * nJl;
         for (int p = 0; p < nP; ++p) {
             const double *Bp = h->Bhat + p * nJl; double s = 0.0;

@@ -53,6 +53,9 @@ void nfo_local_matrices(const nfo_t *h, int e, double D, double Sigma, double *A
 void nfo_global_J_indices(const nfo_t *h, int ix, int iy, int iz, int *idx);
 void nfo_global_phi_indices(const nfo_t *h, int ix, int iy, int iz, int *idx);
 
+/* NOT in the reference: cut the cells with mask != 0 (ne bytes, NULL = none) out of the domain and put J.n = phi / inv_alpha on the
+ * faces they share with kept cells (before nfo_build).  Only the Schur path honours it; see nf_oracle.c. */
+void nfo_set_void(nfo_t *h, const unsigned char *mask, double inv_alpha);
 int nfo_build(nfo_t *h);                                                      /* src/NeutFEM.cpp:402-457 */
 /* y = C x + B A^-1 B^T x for group g, src/solvers.cpp:535-547 */
 void nfo_schur_apply(nfo_t *h, int g, const double *x, double *y);

@@ -45,6 +45,7 @@ def lib():
         L.nfo_local_matrices.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp]
         L.nfo_global_J_indices.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip]
         L.nfo_global_phi_indices.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip]
+        L.nfo_set_void.argtypes = [vp, C.c_char_p, C.c_double]
         L.nfo_build.restype = C.c_int
         L.nfo_build.argtypes = [vp]
         L.nfo_schur_apply.argtypes = [vp, C.c_int, dp, dp]
@@ -135,6 +136,11 @@ class OracleNeutFEM:
     def set_linear_solver(self, t): self._L.nfo_set_linear_solver(self._h, int(t))
     def reset_flux(self): self._L.nfo_reset_flux(self._h)
     def set_refactor_each_solve(self, on): self._L.nfo_set_refactor_each_solve(self._h, int(on))
+
+    def set_void(self, mask, inv_alpha):
+        """NOT in the reference: cut cells out of the domain, J.n = phi / inv_alpha on their faces (before BuildMatrices)"""
+        m = np.ascontiguousarray(mask, dtype=np.uint8).ravel(); assert m.size == self.ne
+        self._L.nfo_set_void(self._h, m.tobytes(), float(inv_alpha))
 
     def BuildMatrices(self):
         rc = self._L.nfo_build(self._h)

@@ -1,0 +1,31 @@
+#!/bin/bash
+# round 4, call d: single-reduction CG in the 8-slab loopback at 256^3 after the one-wave-per-row reduce kernel; A/B of the waves-per-SIMD
+# targets of its two z passes (scratch/libs: -DNF_SR_Z1_WAVES=2, -DNF_SR_Z2_WAVES=3), same box, per-kernel durations by rocprofv3
+OUT=gpurun_out/r04_d; mkdir -p $OUT; export TMPDIR=/tmp
+B="--steps 3 --warmup 1 --cpu-sample-iters 0 --no-converge --no-parity --no-small --no-c5 --loopback-slabs 8"
+run() {  # label, opts, lib
+  NEUTFEM_HIP_LIB="$3" NEUTFEM_OPTS="$2" timeout -k 10 300 python bench.py $B > $OUT/b.json 2> $OUT/b.err; rc=$?
+  python - "$1" $rc <<'PY'
+import json, sys
+try:
+    d = json.loads(open("gpurun_out/r04_d/b.json").read().strip().splitlines()[-1]); cg = d["config"]["cg_iters_per_outer"]
+    ps = " ".join(f"{p['name'][-1]} {1e3*p['avg_ms']:.1f}" for p in d["roofline"]["passes"])
+    print(f"{sys.argv[1]:52s} rc {sys.argv[2]} us/CG-it {1e3*d['ms_per_step']/cg:7.1f}  passes(us) {ps}  k {d['keff_after_timed_steps']:.12f}")
+except Exception as e:
+    print(sys.argv[1], "rc", sys.argv[2], "unreadable", e)
+PY
+}
+run "two reductions (reference recurrence)" "cg_single_reduce=0" ""
+run "single reduction, z1 3 waves / z2 4 waves (default)" "cg_single_reduce=1" ""
+run "single reduction, z1 2 waves" "cg_single_reduce=1" "$PWD/scratch/libs/libnf_z1w2.so"
+run "single reduction, z2 3 waves" "cg_single_reduce=1" "$PWD/scratch/libs/libnf_z2w3.so"
+run "single reduction, default build, s_tx=32" "cg_single_reduce=1,s_tx=32" ""
+run "two reductions, s_tx=32" "cg_single_reduce=0,s_tx=32" ""
+NEUTFEM_OPTS="cg_single_reduce=1" timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o st -- python3 bench.py $B > $OUT/bench_prof.json 2> $OUT/prof.err; echo "prof rc=$?"
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
+import csv, sys, re
+rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:8]:
+    print(f"{re.sub(r'^void nf::','',r['Name'])[:80]:80s} calls {int(r['Calls']):6d} avg {float(r['AverageNs'])/1e3:8.2f} us {float(r['Percentage']):5.1f} %")
+PY
+rm -rf $OUT/prof/*/*kernel_trace.csv $OUT/prof/*kernel_trace.csv

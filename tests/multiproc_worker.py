@@ -42,6 +42,10 @@ def main():
     assert t.head.info("n_ranks") == world and t.head.info("rank") == rank
     if os.environ.get("NEUTFEM_TEST_VEC_REDUCE") is not None:     # A/B of the vector all-reduce of block partials (nf_set_option "vec_reduce")
         t.head.set_option("vec_reduce", int(os.environ["NEUTFEM_TEST_VEC_REDUCE"]))
+    if os.environ.get("NEUTFEM_TEST_CG1") is not None:            # single-reduction CG on / off (nf_set_option "cg_single_reduce"; default on)
+        t.head.set_option("cg_single_reduce", int(os.environ["NEUTFEM_TEST_CG1"]))
+    if os.environ.get("NEUTFEM_TEST_XCHG_COMM") is not None:      # interface planes on a communicator of their own
+        t.head.set_option("xchg_comm", int(os.environ["NEUTFEM_TEST_XCHG_COMM"]))
     # 1. distributed Schur apply
     xg = np.random.default_rng(4).standard_normal((nz, ny, nx))
     y = t.schur_apply(1, xg[k0:k1]) if rt == 0 else np.zeros((k1 - k0, ny, nx))
@@ -58,7 +62,9 @@ def main():
     J = t.get_J_local() if (not use_diag and rt == 0) else None                 # collective: the z currents cross slabs
     ys = [None] * world; ps = [None] * world; ks = [None] * world; js = [None] * world
     vec = t.head.info("vec_reduce")                               # 1: the last CG solve all-reduced the partial vectors themselves (no k_finalize)
-    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n, vec), ks if rank == 0 else None)
+    red = t.head.info("cg_reductions")                            # cross-rank reductions per CG iteration of the last CG solve (1: single-reduction CG)
+    xc = t.head.info("xchg_comm")
+    dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(phi, ps if rank == 0 else None); dist.gather_object((k, n, vec, red, xc), ks if rank == 0 else None)
     dist.gather_object((J, k1 - k0), js if rank == 0 else None)
     if rank == 0:
         extra = {}
@@ -71,7 +77,7 @@ def main():
                 zs.append(z if r == world - 1 else z[:, :-1])
             extra["J"] = np.concatenate([np.concatenate(xs, axis=1), np.concatenate(ysf, axis=1), np.concatenate(zs, axis=1).reshape(2, -1)], axis=1)
         np.savez(out, y=np.concatenate(ys, axis=0), phi=np.concatenate(ps, axis=1), k=np.array([v[0] for v in ks]), n=np.array([v[1] for v in ks]),
-                 vec=np.array([v[2] for v in ks]), x=xg, **extra)
+                 vec=np.array([v[2] for v in ks]), red=np.array([v[3] for v in ks]), xc=np.array([v[4] for v in ks]), x=xg, **extra)
     dist.barrier()
     t.close()
     dist.destroy_process_group()

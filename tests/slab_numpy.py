@@ -165,3 +165,24 @@ def distributed_cg(op, b, tol, maxit, comm):
         if rrn < tol_sq: break
         p = r + (rrn / rr) * p; rr = rrn
     return x, its
+
+
+def distributed_cg_single_reduction(op, b, tol, maxit, comm):
+    """The same solve with ONE all-reduce per iteration (Cg1 in neutfem_amd/csrc/nf_kernels.h, what slab teams run by default): the
+    reduction of iteration j carries [p.q, q.q, r.q, |r_j|^2 measured]; its consumer forms alpha_j, the predicted
+    |r_{j+1}|^2 = |r|^2 - 2 alpha r.q + alpha^2 q.q (for beta_j only) and applies r -= alpha q, x += alpha p, p = r + beta p in one sweep;
+    the stop test is taken on the measured |r_j|^2, one apply late, so the returned x is the one the reference recurrence returns."""
+    x = np.zeros_like(b); r = b.copy(); p = b.copy()
+    tol_sq = tol * tol * comm.allreduce(float((b * b).sum()))
+    for j in range(maxit + 1):
+        q = op.apply(p)
+        pq, qq, rq, rr = comm.allreduce4([float((p * q).sum()), float((q * q).sum()), float((r * q).sum()), float((r * r).sum())])
+        if j >= 1 and rr < tol_sq: return x, j
+        if abs(pq) < 1e-30: return x, j
+        al = rr / pq
+        rn = max(rr - 2.0 * al * rq + al * al * qq, 0.0)
+        x += al * p
+        if j + 1 >= maxit: return x, j + 1
+        r -= al * q
+        p = r + (rn / rr) * p
+    return x, maxit

@@ -35,7 +35,12 @@ class GlooComm:
         return r_lo, r_hi
 
     def allreduce(self, v):
-        t = torch.tensor([v], dtype=torch.float64); dist.all_reduce(t); return float(t.item())
+        t = torch.tensor([v], dtype=torch.float64); dist.all_reduce(t); self.n_allreduce += 1; return float(t.item())
+
+    def allreduce4(self, v):
+        t = torch.tensor(v, dtype=torch.float64); dist.all_reduce(t); self.n_allreduce += 1; return [float(a) for a in t]
+
+    n_allreduce = 0
 
 
 def _worker(rank, world, port, shape, seed, out):
@@ -43,7 +48,7 @@ def _worker(rank, world, port, shape, seed, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bench import split_planes
     from helpers import make_oracle, synthetic_inputs
-    from slab_numpy import SlabOperator, distributed_cg
+    from slab_numpy import SlabOperator, distributed_cg, distributed_cg_single_reduction
     nx, ny, nz = shape
     inp = synthetic_inputs(nx, ny, nz, 1, seed=seed, dirichlet=(1, 2, 4, 5, 6))
     k0, k1 = split_planes(nz, world)[rank]
@@ -54,10 +59,12 @@ def _worker(rank, world, port, shape, seed, out):
     xg = rng.standard_normal((nz, ny, nx)); bg = np.abs(rng.standard_normal((nz, ny, nx)))
     y = op.apply(xg[k0:k1])
     sinv = op.diag_sinv()
-    x, its = distributed_cg(op, bg[k0:k1], 1e-10, 2000, GlooComm(rank, world))
+    c2 = GlooComm(rank, world); x, its = distributed_cg(op, bg[k0:k1], 1e-10, 2000, c2)
+    c1 = GlooComm(rank, world); x1, its1 = distributed_cg_single_reduction(op, bg[k0:k1], 1e-10, 2000, c1)
     # gather on rank 0 and compare with the undivided oracle
-    ys = [None] * world; xs = [None] * world; ss = [None] * world
+    ys = [None] * world; xs = [None] * world; ss = [None] * world; x1s = [None] * world
     dist.gather_object(y, ys if rank == 0 else None); dist.gather_object(x, xs if rank == 0 else None); dist.gather_object(sinv, ss if rank == 0 else None)
+    dist.gather_object(x1, x1s if rank == 0 else None)
     tmax = torch.tensor([float(rank + 1)], dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
         o = make_oracle(inp)
@@ -65,8 +72,9 @@ def _worker(rank, world, port, shape, seed, out):
         yo = o.schur_apply(0, xg.ravel()); xo, _, its_o = o.solve_group(0, bg.ravel())
         ya = np.concatenate(ys).ravel(); xa = np.concatenate(xs).ravel()
         so = o.diag_cache(0); sa = np.concatenate(ss).ravel()
+        x1a = np.concatenate(x1s).ravel()
         np.save(out, np.array([np.linalg.norm(ya - yo) / np.linalg.norm(yo), np.linalg.norm(xa - xo) / np.linalg.norm(xo), its, its_o, tmax.item(),
-                               np.abs(sa / so - 1).max()]))
+                               np.abs(sa / so - 1).max(), np.linalg.norm(x1a - xo) / np.linalg.norm(xo), its1, c2.n_allreduce, c1.n_allreduce]))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -78,13 +86,17 @@ def _free_port():
 def test_slab_partition_method_gloo(world, shape, tmp_path):
     out = str(tmp_path / "res.npy")
     mp.spawn(_worker, args=(world, _free_port(), shape, 11, out), nprocs=world, join=True)
-    err_apply, err_solve, its, its_o, tmax, err_sinv = np.load(out)
+    err_apply, err_solve, its, its_o, tmax, err_sinv, err_solve1, its1, nred2, nred1 = np.load(out)
     # 2 slabs: exact for any thickness.  3 slabs: the middle slab (33 planes) is thick enough that its two separators
     # decouple to rounding (0.268^32); thinner middle slabs are refused by the HIP path (test_gpu_slabs.py)
     assert err_apply < 1e-12, err_apply
     assert err_solve < 1e-8 and abs(its - its_o) <= max(2, 0.05 * its_o)
     assert tmax == world                       # max-over-ranks reduction used for the bench timing
     assert err_sinv < 1e-13                    # diagonal-Schur cache on slabs (one edge plane per interface)
+    # single-reduction CG (what slab teams run by default): the same answer, the reference's iteration count to within the spread two
+    # correct summation orders show on these 170-iteration solves, half the all-reduces
+    assert err_solve1 < 1e-8 and abs(its1 - its) <= max(2, 0.03 * its), (err_solve1, its1, its)
+    assert nred2 == 2 * its + 1 and nred1 == its1 + 2, (nred2, nred1, its, its1)    # + |b|^2; the single-reduction form pays one apply to see the measured stop
 
 
 def test_split_planes():

@@ -72,9 +72,9 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     o = make_oracle(inp)
     assert rel_l2(res["y"].ravel(), o.schur_apply(1, res["x"].ravel())) < 1e-12
     assert np.ptp(res["k"]) == 0.0 and np.ptp(res["n"]) == 0          # every rank returns the same k and outer count
-    # one slab per rank, equal slabs, full Schur path: the block partials themselves were all-reduced (5 kernels per CG iteration and
-    # rank instead of 7); several slabs per rank or the diagonal path: the k_finalize route
-    assert (res["vec"] == (1 if (per == 1 and use_diag == 0) else 0)).all(), res["vec"]
+    # full Schur path: single-reduction CG -- ONE all-reduce per CG iteration (4 kernels + k_finalize per rank), also with several slabs per rank
+    if use_diag == 0:
+        assert (res["red"] == 1).all() and (res["vec"] == 0).all(), (res["red"], res["vec"])
     s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)       # the same fixed work, undivided
     ks, ns = (s.solve_keff(use_diag=True, use_cmfd=use_diag == 2)) if use_diag else s.solve_keff(True, [2, 1, 2])
     assert int(res["n"][0]) == ns == 16
@@ -85,20 +85,23 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     s.close()
 
 
-def test_vector_reduce_matches_the_scalar_route(tmp_path):
-    """the same 3-rank solve with the vector all-reduce of block partials off (k_finalize + 2-double all-reduces): same outer count,
-    k and flux to rounding (the two routes sum the same partials in a different order)"""
+def test_reduction_routes_agree(tmp_path):
+    """the same 3-rank solve through the three reduction routes of the CG on slab teams: single-reduction CG (default: one all-reduce of
+    five doubles per iteration, interface planes on a communicator of their own here), and the reference recurrence with its two
+    reductions per iteration as vectors of block partials or as scalars behind k_finalize: same outer count, k and flux to rounding"""
     outs = []
-    for flag in ("1", "0"):
-        e = _env(); e["NEUTFEM_TEST_VEC_REDUCE"] = flag
-        out = str(tmp_path / f"res{flag}.npz")
+    for cg1, vec, xc in (("1", "1", "1"), ("0", "1", "0"), ("0", "0", "0")):
+        e = _env(); e["NEUTFEM_TEST_CG1"] = cg1; e["NEUTFEM_TEST_VEC_REDUCE"] = vec; e["NEUTFEM_TEST_XCHG_COMM"] = xc
+        out = str(tmp_path / f"res{cg1}{vec}.npz")
         bad, logs = _run_ranks(3, [out, 1, 0, 16], tmp_path, env=e)
         assert bad is None, bad + "\n" + logs
         outs.append(np.load(out))
-    a, b = outs
-    assert (a["vec"] == 1).all() and (b["vec"] == 0).all()
-    assert int(a["n"][0]) == int(b["n"][0]) and abs(a["k"][0] - b["k"][0]) / b["k"][0] < 1e-11
-    assert rel_l2(a["phi"].ravel(), b["phi"].ravel()) < 1e-9
+    a, b, c = outs
+    assert (a["red"] == 1).all() and (a["vec"] == 0).all() and (a["xc"] == 1).all()
+    assert (b["red"] == 2).all() and (b["vec"] == 1).all() and (b["xc"] == 0).all() and (c["red"] == 2).all() and (c["vec"] == 0).all()
+    for x in (a, b):
+        assert int(x["n"][0]) == int(c["n"][0]) and abs(x["k"][0] - c["k"][0]) / c["k"][0] < 1e-11
+        assert rel_l2(x["phi"].ravel(), c["phi"].ravel()) < 1e-9
 
 
 def test_two_ranks_rt1p1(tmp_path):
@@ -132,8 +135,9 @@ def test_indivisible_coarse_factors_are_refused_by_every_rank(tmp_path):
 
 
 @pytest.mark.parametrize("route,inject,extra,env_extra", [
-    ("vector reduce (RT0-P0, one slab per rank)", "1:40", [], {}),
-    ("scalar reduce (k_finalize + 2-double all-reduce)", "1:40", [], {"NEUTFEM_TEST_VEC_REDUCE": "0"}),
+    ("single-reduction CG (RT0-P0 teams' default: one 5-double all-reduce per iteration)", "1:40", [], {}),
+    ("vector reduce (two reductions per iteration, one slab per rank)", "1:40", [], {"NEUTFEM_TEST_CG1": "0"}),
+    ("scalar reduce (k_finalize + 2-double all-reduce)", "1:40", [], {"NEUTFEM_TEST_CG1": "0", "NEUTFEM_TEST_VEC_REDUCE": "0"}),
     ("RT1-P1 team (k_finalize + k_cg_logic, no lean CG)", "1:25:4", [0, 1], {})])
 def test_failing_rank_stops_every_rank_instead_of_hanging_them(tmp_path, route, inject, extra, env_extra):
     """a rank-local error inside a solve used to return on that rank only -- the others then waited in
