@@ -341,9 +341,11 @@ def main():
         hits = [k for k in pmc if re.match(pat, k)]
         key = max(hits, key=lambda k: pmc[k].get("dispatches", 0)) if hits else None
         fresh = pj.get("kernel_source_sha256") == cur
-        if a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc and not fresh:
+        if os.environ.get("NEUTFEM_OPTS"):
+            traffic_source = dict(file="profiles/" + prof, stale=True, why="NEUTFEM_OPTS overrides launch parameters: this is not the run that was profiled: traffic = null")
+        elif a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc and not fresh:
             # the newest committed profile was taken with other kernel sources: no figure rather than a stale one
-            traffic_source = dict(file="profiles/" + prof, stale=True, why="the device kernels changed since this profile was collected (sha256 of nf_kernels.h differs): traffic = null")
+            traffic_source = dict(file="profiles/" + prof, stale=True, why="the kernels or their launch logic changed since this profile was collected (sha256 of nf_kernels.h + nf_assembly.h + neutfem_hip.hip differs): traffic = null")
         elif a.n == 256 and a.case == "iaea3d" and slabs_total == 1 and key in pmc:
             traffic = round(pmc[key]["hbm_bytes_per_cell"] * N)
             traffic_source = dict(file="profiles/" + prof, kernel=key, measured_in_this_run=False, kernel_sources_match=True,

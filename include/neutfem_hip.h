@@ -26,7 +26,11 @@ typedef struct nf_solver *nf_handle;
 enum { NF_OK = 0, NF_ERR_ARG = -1, NF_ERR_NO_DEVICE = -2, NF_ERR_HIP = -3, NF_ERR_UNSUPPORTED = -4,
        NF_ERR_STATE = -5, NF_ERR_NUMERIC = -6,
        NF_ERR_REMOTE = -7,   /* multi-rank team: another rank hit an error inside a solve; every rank returns at the same iteration */
-       NF_ERR_COMM = -8 };   /* multi-rank team: a collective did not complete within NEUTFEM_COMM_TIMEOUT_S (a peer is gone or stuck) */
+       NF_ERR_COMM = -8 };   /* multi-rank team: a collective did not complete within NEUTFEM_COMM_TIMEOUT_S (a peer is gone or stuck).  The team is
+                              * dead afterwards: its streams may hold collectives that never finish, so every further collective call on it
+                              * returns NF_ERR_COMM at once and nf_destroy releases the host objects WITHOUT waiting for or freeing device
+                              * resources.  The caller must end the process with a non-zero code (a fresh exit -- never an exec of another
+                              * program from this process) */
 /* BCType, include/NeutFEM.hpp:51-57 */
 enum { NF_BC_DIRICHLET = 0, NF_BC_NEUMANN = 1, NF_BC_MIRROR = 2, NF_BC_ROBIN = 3, NF_BC_PERIODIC = 4 };
 

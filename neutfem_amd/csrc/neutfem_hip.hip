@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -136,11 +137,13 @@ struct nf_team {
     // undivided mesh -- the two one-block k_finalize launches per CG iteration leave the critical path (7 -> 5 kernels per rank).
     double *d_vec = nullptr; long vec_stride = 0;          // 2 rows: all-reduced p.q partials, all-reduced |r|^2 partials (+ flag slot each)
     int vec_cnt_pq = 0, vec_cnt_rr = 0; bool vec_ok = false; int opt_vec_reduce = 1, last_vec_reduce = 0;
+    bool dead = false;              // a collective timed out (NF_ERR_COMM): the streams may hold operations that never complete -- no further solve, no stream waits at teardown
     bool dry = false;               // launch functions only report their partial counts
     bool poisoned = false; int poison_rc = 0; char poison_msg[256] = { 0 };
     int xchg_in_apply = 0;          // interface exchanges issued since the current Schur apply began
     long cg_iter_total = 0;         // CG iterations launched since the team was created (NEUTFEM_INJECT_FAIL=<rank>:<iteration>)
     int inject_rank = -1; long inject_iter = -1;
+    int inject_outer = -1; char inject_where = 0;   // NEUTFEM_INJECT_FAIL=<rank>:o<n> / :e<n> (start / end of outer n, outside the CG loop), :a (next exchange-only collective)
     double comm_timeout_s = 120.0;  // multi-rank teams: a stream that does not drain for this long means a peer is gone (NEUTFEM_COMM_TIMEOUT_S)
     volatile long outers_done = 0;  // completed outer iterations of the running / last SolveKeff (bench.py's watchdog polls it from another thread)
     bool linked_ready = false;      // separator diagonals exchanged
@@ -361,9 +364,12 @@ static int team_alloc(nf_team *T)
     // NEUTFEM_INJECT_FAIL=<rank>:<iteration>[:<min local DOFs per cell>] (tests): the optional third field keeps the injection away from
     // the RT0-P0 coarse twin of a higher-order team, so that the non-lean reduction route of RT1 / RT2 teams is the one that is hit
     if (const char *e = getenv("NEUTFEM_INJECT_FAIL")) {
-        int r = -1, ml = 0; long it = -1;
-        const int nf = sscanf(e, "%d:%ld:%d", &r, &it, &ml);
-        if (nf >= 2 && (nf < 3 || T->slabs.empty() || T->slabs[0]->nloc >= ml)) { T->inject_rank = r; T->inject_iter = it; }
+        int r = -1, ml = 0; long it = -1; char w = 0; int on = -1;
+        if (sscanf(e, "%d:%c%d", &r, &w, &on) >= 2 && (w == 'o' || w == 'e' || w == 'a')) { T->inject_rank = r; T->inject_where = w; T->inject_outer = on; }
+        else {
+            const int nf = sscanf(e, "%d:%ld:%d", &r, &it, &ml);
+            if (nf >= 2 && (nf < 3 || T->slabs.empty() || T->slabs[0]->nloc >= ml)) { T->inject_rank = r; T->inject_iter = it; }
+        }
     }
     if (const char *e = getenv("NEUTFEM_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0) T->comm_timeout_s = v; }
     T->last_its.assign(64, 0);
@@ -373,6 +379,12 @@ static void team_free(nf_team *T)
 {
     if (!T) return;
     (void)hipSetDevice(T->device);
+    if (T->dead) {
+        // after NF_ERR_COMM the streams hold collectives whose peers are gone: waiting for them, destroying them or the communicator can
+        // block for ever.  Everything of this team is left to the process exit, which the caller owes anyway (include/neutfem_hip.h).
+        delete T;
+        return;
+    }
     if (T->stream) (void)hipStreamSynchronize(T->stream);
     for (auto &e : T->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : T->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -509,6 +521,14 @@ int nf_destroy(nf_handle S)
     if (!S) return NF_OK;
     (void)hipSetDevice(S->device);
     nf_team *T = S->team;
+    if (T && T->dead) {                                          // see team_free: nothing of a dead team is waited for or freed (hipFree drains the device)
+        std::vector<nf_solver *> cc; cc.swap(T->cc);
+        for (auto *c : cc) if (c) nf_destroy(c);
+        T->slabs.erase(std::remove(T->slabs.begin(), T->slabs.end(), S), T->slabs.end());
+        if (T->slabs.empty()) team_free(T);
+        delete S;
+        return NF_OK;
+    }
     coarse_cache_drop(T);
     if (T && T->stream) (void)hipStreamSynchronize(T->stream);
     for (int d = 0; d < 3; ++d) { dfree(S->d_Dt[d]); dfree(S->d_Dh[d]); }
@@ -802,8 +822,10 @@ static int team_stream_wait(nf_team *T, hipStream_t st)
         if (q != hipErrorNotReady) { HIPCHK(q); }
         if (i > 2000) usleep(i > 20000 ? 200 : 20);
         if ((i & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > T->comm_timeout_s) {
-            if (g_rccl.CommAbort && T->comm_x) { (void)g_rccl.CommAbort(T->comm_x); T->comm_x = nullptr; }
-            if (g_rccl.CommAbort && T->comm) { (void)g_rccl.CommAbort(T->comm); T->comm = nullptr; }
+            if (g_rccl.CommAbort && T->comm_x) { (void)g_rccl.CommAbort(T->comm_x); }
+            if (g_rccl.CommAbort && T->comm) { (void)g_rccl.CommAbort(T->comm); }
+            T->comm = nullptr; T->comm_x = nullptr; T->dead = true;   // with or without ncclCommAbort the queued collectives may never finish: the team is unusable from here on
+            for (auto *c : T->cc) if (c && c->team) { c->team->comm = nullptr; c->team->comm_x = nullptr; c->team->dead = true; }   // the coarse twin borrowed the same communicator
             return fail(NF_ERR_COMM, "rank %d: a collective did not complete within %.0f s (NEUTFEM_COMM_TIMEOUT_S): a peer rank is gone or stuck", T->rank, T->comm_timeout_s);
         }
     }
@@ -1015,7 +1037,8 @@ static int team_prepare(nf_team *T)
 }
 
 // process-local sum of the partials (+ all-reduce over ranks) + the scalar logic of `op`
-static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int nq, double *out, double tol, int maxit)
+// want_flag (FIN_SUM on a multi-rank team): the all-reduced error flags of the ranks land in out[nq], next to the sums (0 elsewhere)
+static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int nq, double *out, double tol, int maxit, bool want_flag = false)
 {
     PartSegs ps = segs_for(T, counts);
     if (!T->rccl_reduce) {
@@ -1025,8 +1048,52 @@ static int team_finalize(nf_team *T, int op, const std::vector<int> &counts, int
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, T->stream, op, T->d_partials, ps, T->partial_stride, nq, T->d_cg, out, tol, maxit, 1, T->d_red, (const double *)T->d_errsrc);
         TRACE_COMM("rank %d allreduce finalize op=%d count=%d poisoned=%d", T->rank, op, nq + 1, (int)T->poisoned);
         NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, (size_t)nq + 1, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream));
-        hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, T->stream, op, T->d_red, nq, T->d_cg, out, tol, maxit, 1);
+        hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, T->stream, op, T->d_red, nq, T->d_cg, out, tol, maxit, want_flag ? 2 : 1);
     }
+    return NF_OK;
+}
+
+// A rank-local failure on a multi-rank team OUTSIDE the CG loop (an allocation, a refused launch between two collectives of the outer
+// iteration): the rank raises its flag and carries on with the schedule instead of returning -- its peers are about to enter the next
+// collective.  The flag travels in the reductions that exist anyway: the next CG solve ends on every rank at its first reduction
+// (cg_logic, FIN_RHS), the per-outer reduction hands the flags to the host (team_finalize, want_flag).  Returns true when the caller
+// must return `code` at once (single process).
+static bool team_poison(nf_team *T, int code)
+{
+    if (code == NF_OK) return false;
+    if (T->nproc <= 1) return true;
+    if (!T->poisoned) {
+        T->poisoned = true; T->poison_rc = code; snprintf(T->poison_msg, sizeof T->poison_msg, "%s", nf_last_error());
+        const double one = 1.0;
+        (void)hipMemcpyAsync(T->d_errsrc, &one, sizeof one, hipMemcpyHostToDevice, T->stream);
+        (void)hipStreamSynchronize(T->stream);
+        (void)hipGetLastError();
+    }
+    return false;
+}
+static int team_poison_result(nf_team *T)                         // the poisoned rank's own error, once every rank has stopped
+{
+    const int code = T->poison_rc; char msg[256]; snprintf(msg, sizeof msg, "%s", T->poison_msg);
+    T->poisoned = false;
+    (void)hipMemsetAsync(T->d_errsrc, 0, sizeof(double), T->stream);
+    return fail(code, "%s", msg);
+}
+// Exchange-only collectives (nf_build_diagonal_cache, nf_get_J, nf_initialize_cmfd: planes travel, nothing is reduced): every rank does
+// its fallible local work first (allocations), then the verdicts are all-reduced, and only if every rank is fine is the first plane
+// posted -- a rank that failed would otherwise return while its neighbours wait in ncclRecv until the timeout.
+static int team_verdict(nf_team *T, int local_rc, const char *what)
+{
+    if (T->nproc > 1 && T->rank == T->inject_rank && T->inject_where == 'a') { T->inject_where = 0; local_rc = fail(NF_ERR_HIP, "injected failure on rank %d before %s (NEUTFEM_INJECT_FAIL)", T->rank, what); }
+    if (!(T->rccl_reduce && T->nproc > 1)) return local_rc;
+    std::string keep = local_rc != NF_OK ? g_err : std::string();
+    double v = local_rc != NF_OK ? 1.0 : 0.0;
+    HIPCHK(hipMemcpyAsync(T->d_red, &v, sizeof v, hipMemcpyHostToDevice, T->stream));
+    TRACE_COMM("rank %d allreduce verdict before %s", T->rank, what);
+    NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
+    HIPCHK(hipMemcpyAsync(&v, T->d_red, sizeof v, hipMemcpyDeviceToHost, T->stream));
+    NFCHK(team_stream_wait(T, T->stream));
+    if (local_rc != NF_OK) { g_err = keep; return local_rc; }
+    if (v != 0.0) return fail(NF_ERR_REMOTE, "another rank of the team reported an error before %s; no rank started it", what);
     return NF_OK;
 }
 
@@ -1057,11 +1124,15 @@ static int team_reduce_sr(nf_team *T, const std::vector<int> &counts)
 static bool lds_opt_in(const void *fn, size_t lds)
 {
     if (lds <= 64 * 1024) return true;
-    static std::map<const void *, size_t> granted;
-    auto it = granted.find(fn);
+    // the attribute belongs to the CURRENT device's copy of the function: a process that holds handles on two devices must ask on each
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    static std::mutex mu;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find({ dev, fn });
     if (it != granted.end() && it->second >= lds) return true;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return false; }
-    granted[fn] = lds;
+    granted[{ dev, fn }] = lds;
     return true;
 }
 // ---- Schur apply -----------------------------------------------------------------------------
@@ -1165,8 +1236,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
             const bool nt = T->opt_nt_loads && S->N > T->nt_min_cells;
             const int xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : (d == 1 && nt);
             bool launched = false;                                    // false: the device refused the LDS -> the one-chunk kernel below
-#define NF_C(DIRV, NTV) do { if (lds_opt_in((const void *)k_schur_c<DIRV, NTV>, ldsc)) { launched = true; \
-            hipLaunchKernelGGL((k_schur_c<DIRV, NTV>), grid, block, ldsc, T->stream, ma.x[0], ma.y[0], ma.Ta, L, DR, D0, n, sl, ostride, S->nx, TXc, NS, last, partials, cg, xcd); } } while (0)
+#define NF_C(DIRV, NTV) do { if (lds_opt_in((const void *)k_schur_c<DIRV, NTV>, ldsc)) { \
+            hipLaunchKernelGGL((k_schur_c<DIRV, NTV>), grid, block, ldsc, T->stream, ma.x[0], ma.y[0], ma.Ta, L, DR, D0, n, sl, ostride, S->nx, TXc, NS, last, partials, cg, xcd); \
+            launched = hipGetLastError() == hipSuccess; } } while (0)   /* a refused launch (LDS, block size) falls through to the one-chunk kernel */
             if (d == 1) { if (nt) NF_C(1, true); else NF_C(1, false); } else { if (nt) NF_C(2, true); else NF_C(2, false); }
 #undef NF_C
             if (launched) { if (nparts) *nparts = (int)(grid.x * grid.y); return NF_OK; }
@@ -1379,6 +1451,7 @@ int nf_schur_apply(nf_handle S, int g, const double *x_dev, double *y_dev)
 int nf_team_schur_apply(nf_handle S, int g, const double *const *x_dev, double *const *y_dev)
 {
     if (!S || !x_dev || !y_dev || g < 0 || g >= S->ng) return fail(NF_ERR_ARG, "nf_team_schur_apply: bad arguments");
+    if (S->team->dead) return fail(NF_ERR_COMM, "this team lost a collective (NF_ERR_COMM) and is unusable: destroy the handles and end the process with a non-zero code (never re-exec)");
     nf_team *T = S->team;
     HIPCHK(hipSetDevice(T->device));
     NFCHK(team_prepare(T));
@@ -1799,7 +1872,11 @@ int nf_build_diagonal_cache(nf_handle S)
     for (auto *X : T->slabs) { valid &= X->diag_valid; any_if |= X->if_lo || X->if_hi; }
     if (valid) return NF_OK;
     HIPCHK(hipSetDevice(S->device));
-    for (auto *X : T->slabs) NFCHK(dalloc(&X->d_Sinv, (size_t)X->N * X->ng));
+    {
+        int lrc = NF_OK;
+        for (auto *X : T->slabs) if (lrc == NF_OK && !X->d_Sinv) lrc = dalloc(&X->d_Sinv, (size_t)X->N * X->ng);
+        NFCHK(team_verdict(T, lrc, "the edge-plane exchange of nf_build_diagonal_cache"));
+    }
     for (int g = 0; g < S->ng; ++g) {
         if (any_if) {
             for (auto *X : T->slabs) {
@@ -1883,12 +1960,18 @@ static int team_reconstruct_Jz(nf_team *T)
     if (all) return NF_OK;
     NFCHK(team_prepare(T));
     const int ns = (int)T->slabs.size(), ng = T->slabs[0]->ng;
+    {
+        int lrc = NF_OK;
+        for (auto *S : T->slabs) {
+            if (lrc == NF_OK && !S->d_Jz) lrc = dalloc(&S->d_Jz, (size_t)S->nJz * ng);
+            if (lrc == NF_OK && S->k > 0 && !S->d_Jzb) { int ni = S->k; for (int t = 1; t < S->dim; ++t) ni *= S->k + 1; lrc = dalloc(&S->d_Jzb, (size_t)S->N * ni * ng); }
+        }
+        NFCHK(team_verdict(T, lrc, "the partition-method solve of nf_get_J"));
+    }
     for (auto *S : T->slabs) {
-        if (!S->d_Jz) NFCHK(dalloc(&S->d_Jz, (size_t)S->nJz * ng));
         HIPCHK(hipMemsetAsync(S->d_Jz, 0, (size_t)S->nJz * ng * sizeof(double), T->stream));         // RT modes that see no phi moment stay 0
         if (S->k > 0) {
             int ni = S->k; for (int t = 1; t < S->dim; ++t) ni *= S->k + 1;
-            if (!S->d_Jzb) NFCHK(dalloc(&S->d_Jzb, (size_t)S->N * ni * ng));
             HIPCHK(hipMemsetAsync(S->d_Jzb, 0, (size_t)S->N * ni * ng * sizeof(double), T->stream));
         }
     }
@@ -1917,7 +2000,11 @@ static int team_reconstruct_Jz_diag(nf_team *T)
     NFCHK(team_prepare(T));
     const int ng = T->slabs[0]->ng;
     hipStream_t st = T->stream;
-    for (auto *S : T->slabs) if (!S->d_Jz) NFCHK(dalloc(&S->d_Jz, (size_t)S->nJz * ng));
+    {
+        int lrc = NF_OK;
+        for (auto *S : T->slabs) if (lrc == NF_OK && !S->d_Jz) lrc = dalloc(&S->d_Jz, (size_t)S->nJz * ng);
+        NFCHK(team_verdict(T, lrc, "the edge-plane exchanges of nf_get_J (diagonal path)"));
+    }
     for (int g = 0; g < ng; ++g) {
         // (1) a2 of the edge cells -> d_rlo / d_rhi ; kept in d_ctlo / d_cthi while the planes are reused for phi
         for (auto *S : T->slabs) {
@@ -1953,6 +2040,7 @@ static int team_reconstruct_Jz_diag(nf_team *T)
 int nf_get_J(nf_handle S, double *J_host)
 {
     if (!S || !J_host) return fail(NF_ERR_ARG, "nf_get_J: bad arguments");
+    if (S->team->dead) return fail(NF_ERR_COMM, "this team lost a collective (NF_ERR_COMM) and is unusable: destroy the handles and end the process with a non-zero code (never re-exec)");
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const long N = S->N, nJ = S->nJ;
@@ -2261,7 +2349,11 @@ static int cmfd_initialize_team(nf_team *T)
     bool done = true, any_if = false;
     for (auto *S : T->slabs) { done &= S->cmfd_init && S->cmfd_iface; any_if |= S->if_lo || S->if_hi; }
     if (done) return NF_OK;
-    for (auto *S : T->slabs) NFCHK(cmfd_initialize(S));
+    {
+        int lrc = NF_OK;
+        for (auto *S : T->slabs) if (lrc == NF_OK) lrc = cmfd_initialize(S);     // allocations + the slab-local D-tilde
+        if (any_if) NFCHK(team_verdict(T, lrc, "the interface exchange of nf_initialize_cmfd")); else NFCHK(lrc);
+    }
     if (any_if) {
         NFCHK(team_prepare(T));
         hipStream_t st = T->stream;
@@ -2792,19 +2884,26 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         }
     }
     ScatterArgs sa; sa.ng = ng;
-    double hout[4];
+    double hout[5] = { 0, 0, 0, 0, 0 };
     std::vector<int> gN(ns), gT(ns);
     std::vector<const double *> rhs(ns); std::vector<double *> sol(ns);
     for (int i = 0; i < ns; ++i) { gN[i] = grid_for(T->slabs[i]->nphi); gT[i] = grid_for(T->slabs[i]->nphi * ng); }
+    const bool multi = T->nproc > 1;
+    // multi-rank teams: a rank-local failure between two collectives of the outer iteration poisons the rank instead of ending its part
+    // of the schedule (team_poison); every rank then leaves at the same point -- the first reduction of the next CG solve, or the
+    // per-outer reduction, whichever comes first
+#define NF_OUTER_CHK(x) do { const int r_ = (x); if (team_poison(T, r_)) return r_; } while (0)
     for (int it = 0; it < o->max_outer; ++it) {
+        if (multi && T->rank == T->inject_rank && T->inject_where == 'o' && it == T->inject_outer)
+            NF_OUTER_CHK(fail(NF_ERR_HIP, "injected failure on rank %d at the start of outer iteration %d (NEUTFEM_INJECT_FAIL)", T->rank, it));
         // total_fiss and prod_old (:1700-1707)
-        for (int i = 0; i < ns; ++i) {
+        for (int i = 0; i < ns && !T->poisoned; ++i) {
             nf_solver *S = T->slabs[i];
             hipLaunchKernelGGL(k_fission, dim3(gN[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_phi, ng, S->nphi, S->d_tf, T->d_partials + i * T->slab_cap, (const double *)nullptr, 0L);
         }
-        NFCHK(team_finalize(T, FIN_SUM, gN, 1, T->d_out, 0.0, 0));
+        NF_OUTER_CHK(team_finalize(T, FIN_SUM, gN, 1, T->d_out, 0.0, 0));
         for (int g = 0; g < ng; ++g) {
-            for (int i = 0; i < ns; ++i) {
+            for (int i = 0; i < ns && !T->poisoned; ++i) {
                 nf_solver *S = T->slabs[i]; const long N = S->N, NP = S->nphi;
                 for (int gp = 0; gp < 64; ++gp) sa.M[gp] = gp < ng ? S->d_Ms[g * ng + gp] : nullptr;
                 double *dst = use_diag ? S->d_raw + g * NP : S->d_rhs;
@@ -2825,14 +2924,20 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
             }
             T->hist_cg.push_back(its); T->last_cg_total += its;
         }
-        if (use_cmfd && it >= 2) { if (single) NFCHK(cmfd_step(S0, keff, use_diag)); else NFCHK(cmfd_step_team(T, keff, use_diag)); }   // :1750-1761
+        if (use_cmfd && it >= 2 && !T->poisoned) { if (single) NFCHK(cmfd_step(S0, keff, use_diag)); else NFCHK(cmfd_step_team(T, keff, use_diag)); }   // :1750-1761
+        if (multi && T->rank == T->inject_rank && T->inject_where == 'e' && it == T->inject_outer)
+            NF_OUTER_CHK(fail(NF_ERR_HIP, "injected failure on rank %d at the end of outer iteration %d (NEUTFEM_INJECT_FAIL)", T->rank, it));
         // prod_new, norms (:1766-1779)
-        for (int i = 0; i < ns; ++i) {
+        for (int i = 0; i < ns && !T->poisoned; ++i) {
             nf_solver *S = T->slabs[i];
             hipLaunchKernelGGL(k_outer_reduce, dim3(gT[i]), dim3(256), 0, T->stream, S->d_Mf, S->d_raw, S->d_phi, S->nphi * ng, T->d_partials + i * T->slab_cap, T->partial_stride);
         }
-        NFCHK(team_finalize(T, FIN_SUM, gT, 3, T->d_out + 1, 0.0, 0));
-        NFCHK(readback(T, nullptr, nullptr, T->d_out, hout, 4));
+        NF_OUTER_CHK(team_finalize(T, FIN_SUM, gT, 3, T->d_out + 1, 0.0, 0, true));
+        NFCHK(readback(T, nullptr, nullptr, T->d_out, hout, multi ? 5 : 4));
+        if (multi && (T->poisoned || hout[4] != 0.0)) {            // the ranks' error flags came with the sums: every rank is here, at the same outer
+            if (T->poisoned) return team_poison_result(T);
+            return fail(NF_ERR_REMOTE, "another rank of the team reported an error during outer iteration %d; every rank stopped there", it);
+        }
         const double prod_old = hout[0], prod_new = hout[1], nsq = hout[2], dsq = hout[3];
         const double keff_new = keff * (prod_new / prod_old);
         const double dk = std::fabs(keff_new - keff);
@@ -2850,7 +2955,8 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         }
         for (int i = 0; i < ns; ++i) {
             nf_solver *S = T->slabs[i]; const long NT = S->nphi * ng;
-            if (mode && !S->d_p0) { NFCHK(dalloc(&S->d_p0, (size_t)NT)); NFCHK(dalloc(&S->d_p1, (size_t)NT)); }
+            if (mode && !S->d_p0) { NF_OUTER_CHK(dalloc(&S->d_p0, (size_t)NT)); if (!T->poisoned) NF_OUTER_CHK(dalloc(&S->d_p1, (size_t)NT)); }
+            if (T->poisoned) break;
             hipLaunchKernelGGL(k_normalize_cheb, dim3(gT[i]), dim3(256), 0, T->stream, S->d_raw, S->d_phi, S->d_p0, S->d_p1, NT, norm,
                                norm > 1e-14 ? 1 : 0, mode, a, b);
             if (mode == 3) std::swap(S->d_p0, S->d_p1);
@@ -2859,7 +2965,13 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
         T->last_outer = it + 1;
         __atomic_store_n(&T->outers_done, (long)(it + 1), __ATOMIC_RELEASE);
-        if (dk < o->tol_keff && dphi < o->tol_flux) break;        // :1799-1802
+        if (dk < o->tol_keff && dphi < o->tol_flux && !T->poisoned) break;        // :1799-1802 (a poisoned rank stays in the schedule until the flag has gone round)
+    }
+#undef NF_OUTER_CHK
+    if (T->poisoned) {                                            // poisoned in the last outer the loop ran: one more reduction takes the flag to everybody
+        (void)team_finalize(T, FIN_SUM, gN, 1, T->d_out, 0.0, 0, true);
+        (void)team_stream_wait(T, T->stream);
+        return team_poison_result(T);
     }
     HIPCHK(hipStreamSynchronize(T->stream));
     HIPCHK(hipGetLastError());
@@ -2875,6 +2987,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
 int nf_solve_keff(nf_handle S, const nf_keff_opts *o, double *keff, int *n_outer)
 {
     if (!S || !o) return fail(NF_ERR_ARG, "nf_solve_keff: bad arguments");
+    if (S->team->dead) return fail(NF_ERR_COMM, "this team lost a collective (NF_ERR_COMM) and is unusable: destroy the handles and end the process with a non-zero code (never re-exec)");
     for (auto *X : S->team->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_solve_keff: call nf_build first");
     HIPCHK(hipSetDevice(S->device));
     __atomic_store_n(&S->team->outers_done, 0L, __ATOMIC_RELEASE);
@@ -2896,6 +3009,7 @@ int nf_progress(nf_handle S, long *outers_done)
 int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct, int use_direct_keff, double *keff_adj, int *n_outer)
 {
     if (!S || !o) return fail(NF_ERR_ARG, "nf_solve_adjoint: bad arguments");
+    if (S->team->dead) return fail(NF_ERR_COMM, "this team lost a collective (NF_ERR_COMM) and is unusable: destroy the handles and end the process with a non-zero code (never re-exec)");
     nf_team *T = S->team;
     for (auto *X : T->slabs) if (!X->built) return fail(NF_ERR_STATE, "nf_solve_adjoint: call nf_build first");
     HIPCHK(hipSetDevice(T->device));
@@ -3121,7 +3235,7 @@ int nf_local_matrices(nf_handle S, int g, int n_elems, const int *elems_host, do
     const int nJ = S->dim * (2 * nf + ni); int nP = 1; for (int t = 0; t < S->dim; ++t) nP *= S->m + 1;
     P.nx = S->nx; P.ny = S->ny; P.nz = S->nz; P.hx = S->d_hx; P.hy = S->d_hy; P.hz = S->d_hz;
     P.D = S->d_D + (size_t)g * S->N; P.Sig = S->d_SigR + (size_t)g * S->N; P.n_elems = n_elems;
-    DevTmp<double> dA, dB, dC; int *d_el = nullptr;
+    DevTmp<double> dA, dB, dC; DevTmp<int> dEl; int *&d_el = dEl.p;
     HIPCHK(hipMalloc((void **)&dA.p, (size_t)n_elems * nJ * nJ * sizeof(double))); HIPCHK(hipMalloc((void **)&dB.p, (size_t)n_elems * nP * nJ * sizeof(double)));
     HIPCHK(hipMalloc((void **)&dC.p, (size_t)n_elems * nP * nP * sizeof(double)));
     HIPCHK(hipMalloc((void **)&d_el, (size_t)n_elems * sizeof(int)));
@@ -3149,7 +3263,6 @@ int nf_local_matrices(nf_handle S, int g, int n_elems, const int *elems_host, do
                         hipMemcpy(B_host, dB.p, (size_t)n_elems * nP * nJ * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
                         hipMemcpy(C_host, dC.p, (size_t)n_elems * nP * nP * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess))
         rc = fail(NF_ERR_HIP, "nf_local_matrices: download failed");
-    (void)hipFree(d_el);
     return rc;
 }
 
@@ -3159,18 +3272,24 @@ int nf_time_device_copy(nf_handle S, size_t bytes, int reps, double *gbps)
     HIPCHK(hipSetDevice(S->device));
     hipStream_t st = S->team->stream;
     const long n2 = (long)(bytes / 16);
-    double2 *a = nullptr, *b = nullptr;
+    nf_d2 *a = nullptr, *b = nullptr;
     NFCHK(dalloc(&a, (size_t)n2)); if (dalloc(&b, (size_t)n2) != NF_OK) { dfree(a); return NF_ERR_HIP; }
     (void)hipMemsetAsync(a, 0, (size_t)n2 * 16, st);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     double best = 0.0; hipError_t e = hipSuccess;
-    // best of: plain / nontemporal copy kernels at 8 and 16 blocks per CU, and the runtime's own device-to-device copy
-    for (int variant = 0; variant < 5 && e == hipSuccess; ++variant) {
+    int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, S->device);
+    const bool verbose = getenv("NEUTFEM_COPY_VERBOSE") != nullptr;
+    // best of: plain / non-temporal copy kernels with 4 or 8 16-byte loads in flight per lane at 8, 16, 32 and 64 blocks per CU, and the
+    // runtime's own device-to-device copy
+    const int NV = 17;
+    for (int variant = 0; variant < NV && e == hipSuccess; ++variant) {
         auto once = [&]() {
-            const int grid = 256 * ((variant & 1) ? 16 : 8);
-            if (variant == 4) (void)hipMemcpyAsync(b, a, (size_t)n2 * 16, hipMemcpyDeviceToDevice, st);
-            else if (variant < 2) hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, st, a, b, n2);
-            else hipLaunchKernelGGL(k_copy<true>, dim3(grid), dim3(256), 0, st, a, b, n2);
+            if (variant == NV - 1) { (void)hipMemcpyAsync(b, a, (size_t)n2 * 16, hipMemcpyDeviceToDevice, st); return; }
+            const int grid = ncu * (8 << (variant % 4)); const int kind = variant / 4;
+            if (kind == 0) hipLaunchKernelGGL((k_copy<false, 4>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
+            else if (kind == 1) hipLaunchKernelGGL((k_copy<false, 8>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
+            else if (kind == 2) hipLaunchKernelGGL((k_copy<true, 4>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
+            else hipLaunchKernelGGL((k_copy<true, 8>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
         };
         once();
         (void)hipEventRecord(e0, st);
@@ -3178,7 +3297,11 @@ int nf_time_device_copy(nf_handle S, size_t bytes, int reps, double *gbps)
         (void)hipEventRecord(e1, st);
         e = hipEventSynchronize(e1);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (e == hipSuccess && ms > 0.f) best = std::max(best, 2.0 * (double)n2 * 16.0 * reps / (ms * 1e-3) / 1e9);   // read + write
+        const double gb = ms > 0.f ? 2.0 * (double)n2 * 16.0 * reps / (ms * 1e-3) / 1e9 : 0.0;   // read + write
+        if (verbose) fprintf(stderr, "[copy] variant %2d (%s, %d blocks per CU): %.0f GB/s\n", variant,
+                             variant == NV - 1 ? "hipMemcpyDtoD" : variant / 4 == 0 ? "plain, 4 in flight" : variant / 4 == 1 ? "plain, 8 in flight" : variant / 4 == 2 ? "nt, 4 in flight" : "nt, 8 in flight",
+                             variant == NV - 1 ? 0 : (8 << (variant % 4)), gb);
+        if (e == hipSuccess) best = std::max(best, gb);
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     dfree(a); dfree(b);

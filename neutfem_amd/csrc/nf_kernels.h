@@ -226,6 +226,7 @@ __global__ void k_cg_logic(int op, const double *__restrict__ red, int nq, CgSca
     double tot[4] = { 0, 0, 0, 0 };
     for (int q = 0; q < nq; ++q) tot[q] = red[q];
     cg_logic(op, tot, nq, cg, out, tol, maxit, with_flag ? red[nq] : 0.0);   // red[nq]: the all-reduced error flags of the ranks
+    if (with_flag == 2) out[nq] = red[nq];                       // FIN_SUM of the outer iteration: the host reads the flags next to the sums
 }
 
 // Lean CG (undivided mesh, fused): the two k_finalize launches of an iteration disappear.  The consumer of a reduction sums
@@ -3469,27 +3470,27 @@ __global__ void k_cmfd_correct(const double *__restrict__ x, double *__restrict_
     for (int l = 0; l < nloc; ++l) phi[l * N + e] *= corr;
 }
 
-// streaming copy (HBM microbenchmark for the roofline's "of measured copy" figure): 16-byte accesses, 4 independent
-// loads in flight per thread; NT = nontemporal loads / stores (no reuse, keeps L2 / MALL out of the way)
-template <bool NT>
-__global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, long n2)
+// streaming copy (HBM microbenchmark for the roofline's "of measured copy" figure): 16 bytes per lane and access, U independent loads in
+// flight per lane before the first store, every block walks contiguous chunks of U x 4 KiB (a wave instruction covers 1 KiB); the grid is a
+// multiple of the CU count.  NT = non-temporal loads and stores as whole 16-byte accesses (round 3's NT variant split them into two 8-byte
+// halves and never got past 4.8 TB/s).
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_copy(const nf_d2 *__restrict__ src, nf_d2 *__restrict__ dst, long n2)
 {
-    const long stride = gridDim.x * 256L;
-    long i = blockIdx.x * 256L + threadIdx.x;
-    for (; i + 3 * stride < n2; i += 4 * stride) {
-        double2 v[4];
+    const long chunk = 256L * U;
+    for (long base = (long)blockIdx.x * chunk; base < n2; base += (long)gridDim.x * chunk) {
+        nf_d2 v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (NT) { v[u].x = __builtin_nontemporal_load(&src[i + u * stride].x); v[u].y = __builtin_nontemporal_load(&src[i + u * stride].y); }
-            else v[u] = src[i + u * stride];
+        for (int u = 0; u < U; ++u) {
+            const long i = base + u * 256L + threadIdx.x;
+            if (i < n2) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (NT) { __builtin_nontemporal_store(v[u].x, &dst[i + u * stride].x); __builtin_nontemporal_store(v[u].y, &dst[i + u * stride].y); }
-            else dst[i + u * stride] = v[u];
+        for (int u = 0; u < U; ++u) {
+            const long i = base + u * 256L + threadIdx.x;
+            if (i < n2) { if (NT) __builtin_nontemporal_store(v[u], dst + i); else dst[i] = v[u]; }
         }
     }
-    for (; i < n2; i += stride) dst[i] = src[i];
 }
 
 // input validation on the device (nf_upload_xs): bit `bit` of *flags is raised if the array holds a non-finite value, or

@@ -41,12 +41,14 @@ def counters(root, counter):
 
 
 def kernel_source_hash():
-    """sha256 over the device kernels (nf_kernels.h): bench.py reports a profile's traffic figure only while the kernels are the ones that
-    were profiled (host-side edits of neutfem_hip.hip that leave the kernels alone do not invalidate a profile)"""
+    """sha256 over everything that decides which kernel runs with which shape: the device kernels (nf_kernels.h, nf_assembly.h) AND the host
+    file that picks variants, tile widths, chunking and the streaming-load thresholds (neutfem_hip.hip).  bench.py reports a profile's
+    traffic figure only while all three are the ones that were profiled, and never under NEUTFEM_OPTS (a run with overridden launch
+    parameters is not the run that was profiled)."""
     import hashlib
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for fn in ("nf_kernels.h",):
+    for fn in ("nf_kernels.h", "nf_assembly.h", "neutfem_hip.hip"):
         with open(os.path.join(here, "neutfem_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

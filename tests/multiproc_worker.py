@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_multiproc.py: one rank of a slab-decomposed solve, all ranks on GPU 0, transport =
 tests/fake_rccl (NEUTFEM_RCCL_LIB).  Rendezvous and unique-id broadcast over torch.distributed/gloo, exactly as bench.py.
-usage: multiproc_worker.py <rank> <world> <port> <out.npz> <slabs_per_rank> <use_diag> <planes_per_slab>"""
+usage: multiproc_worker.py <rank> <world> <port> <out.npz> <slabs_per_rank> <use_diag> <planes_per_slab> [<nz or 0> [<rt> [<outers>]]]"""
 import os
 import sys
 
@@ -23,6 +23,7 @@ def main():
     if len(sys.argv) > 8 and int(sys.argv[8]) > 0:
         nz = int(sys.argv[8])                                     # uneven split (e.g. 100 planes on 3 ranks = 33 / 34 / 33)
     rt = int(sys.argv[9]) if len(sys.argv) > 9 else 0            # RT order (P = RT): higher orders exchange one plane per transverse mode
+    outers = int(sys.argv[10]) if len(sys.argv) > 10 else 16      # fixed work of the power iteration (half of it on the coarse twin)
     inp = synthetic_inputs(nx, ny, nz, 2, seed=9, dirichlet=(1, 2, 4, 5, 6))
     allp = split_planes(nz, world * per)
     mine = allp[rank * per:(rank + 1) * per]
@@ -51,7 +52,24 @@ def main():
     y = t.schur_apply(1, xg[k0:k1]) if rt == 0 else np.zeros((k1 - k0, ny, nx))
     # 2. distributed power iteration (coarse-mesh start on the team, borrowed communicator)
     import time
-    t.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)                        # fixed work: 16 fine outers (8 coarse) with tight inner solves
+    if os.environ.get("NEUTFEM_WORKER_LOSE_RANK") is not None:    # a peer that is simply gone (test_a_lost_peer_...): this rank's collectives must time out
+        if rank == int(os.environ["NEUTFEM_WORKER_LOSE_RANK"]):
+            os._exit(7)
+        t.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)
+        t0 = time.time()
+        try:
+            t.solve_keff()
+            print(f"rank {rank}: solve returned although a peer is gone", flush=True); os._exit(1)
+        except RuntimeError as e:
+            print(f"rank {rank}: solve ended after {time.time() - t0:.1f} s: {e}", flush=True)
+        try:
+            t.solve_keff()
+        except RuntimeError as e:
+            print(f"rank {rank}: second solve refused: {e}", flush=True)
+        t1 = time.time(); t.close()
+        print(f"rank {rank}: closed in {time.time() - t1:.2f} s", flush=True)
+        os._exit(5)                                               # a fresh, non-zero exit: what include/neutfem_hip.h asks of the caller after NF_ERR_COMM
+    t.set_tol(1e-12, 1e-9, 1e-9, outers, 2000)                    # fixed work: `outers` fine outers (half as many coarse ones) with tight inner solves
     t0 = time.time()
     if use_diag == 2:                                             # diagonal solver + CMFD: interface D-tilde, halo planes and dots of the PCG across ranks
         k, n = t.solve_keff(use_diag=True, use_cmfd=True)

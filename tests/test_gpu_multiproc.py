@@ -64,7 +64,8 @@ def _run_ranks(world, args, tmp_path, timeout=200, env=None, wait_all=False):
 def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes, tmp_path):
     """planes = 48: coarse slabs of 24 planes need one separator sweep; planes = 12: the fine slabs themselves are thin"""
     out = str(tmp_path / "res.npz")
-    bad, logs = _run_ranks(world, [out, per, use_diag, planes], tmp_path)
+    NO = 8 if use_diag == 0 else 16                                # fixed work: outers of the fine solve (the full path spends half as many on the coarse twin first)
+    bad, logs = _run_ranks(world, [out, per, use_diag, planes, 0, 0, NO], tmp_path)
     assert bad is None, bad + "\n" + logs
     res = np.load(out)
     nz = planes * world * per
@@ -75,9 +76,9 @@ def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes
     # full Schur path: single-reduction CG -- ONE all-reduce per CG iteration (4 kernels + k_finalize per rank), also with several slabs per rank
     if use_diag == 0:
         assert (res["red"] == 1).all() and (res["vec"] == 0).all(), (res["red"], res["vec"])
-    s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, 16, 2000)       # the same fixed work, undivided
+    s = make_hip(inp); s.set_tol(1e-12, 1e-9, 1e-9, NO, 2000)       # the same fixed work, undivided
     ks, ns = (s.solve_keff(use_diag=True, use_cmfd=use_diag == 2)) if use_diag else s.solve_keff(True, [2, 1, 2])
-    assert int(res["n"][0]) == ns == 16
+    assert int(res["n"][0]) == ns == NO
     assert abs(res["k"][0] - ks) / ks < 1e-8
     assert rel_l2(res["phi"].ravel(), s.get_phi().ravel()) < 1e-6
     if not use_diag:                                              # currents: z faces through the partition method across ranks
@@ -93,7 +94,7 @@ def test_reduction_routes_agree(tmp_path):
     for cg1, vec, xc in (("1", "1", "1"), ("0", "1", "0"), ("0", "0", "0")):
         e = _env(); e["NEUTFEM_TEST_CG1"] = cg1; e["NEUTFEM_TEST_VEC_REDUCE"] = vec; e["NEUTFEM_TEST_XCHG_COMM"] = xc
         out = str(tmp_path / f"res{cg1}{vec}.npz")
-        bad, logs = _run_ranks(3, [out, 1, 0, 16], tmp_path, env=e)
+        bad, logs = _run_ranks(3, [out, 1, 0, 16, 0, 0, 6], tmp_path, env=e)   # 6 fine outers (3 coarse), thin slabs: one separator sweep per apply
         assert bad is None, bad + "\n" + logs
         outs.append(np.load(out))
     a, b, c = outs
@@ -157,6 +158,46 @@ def test_failing_rank_stops_every_rank_instead_of_hanging_them(tmp_path, route, 
     assert "another rank of the team reported an error" in per[0] and "another rank of the team reported an error" in per[2], logs
     its = [int(p.split("every rank stopped at iteration ")[1].split()[0].rstrip(".,;)")) for p in (per[0], per[2])]
     assert its[0] == its[1], logs                                 # the same iteration on both healthy ranks
+
+
+@pytest.mark.parametrize("where,inject,use_diag,expect", [
+    ("start of outer 3 of the fine solve's coarse twin (the next CG solve ends everybody at its first reduction)", "1:o3", 0, "every rank stopped at iteration 0"),
+    ("end of outer 2, after the group solves (the per-outer reduction carries the flags to the hosts)", "1:e2", 0, "during outer iteration 2; every rank stopped there"),
+    ("diagonal path, start of outer 5 (no CG: the per-outer reduction is the only collective)", "1:o5", 1, "during outer iteration 5; every rank stopped there"),
+    ("before the partition-method solve of nf_get_J (an exchange-only collective: verdicts are all-reduced first)", "1:a", 0, "no rank started it")])
+def test_failure_outside_the_cg_loop_stops_every_rank(tmp_path, where, inject, use_diag, expect):
+    """a rank that fails BETWEEN two collectives of the outer iteration (an allocation, a refused launch) or on its way
+    into an exchange-only collective used to return alone; its peers then sat in the next collective until NEUTFEM_COMM_TIMEOUT_S.  Now
+    the rank's flag rides in the reductions that exist anyway (first reduction of the next CG solve, per-outer reduction) and exchange-only
+    collectives all-reduce a verdict before the first plane is posted: all three ranks end within seconds, rank 1 with its own error,
+    ranks 0 and 2 with NF_ERR_REMOTE at the same point."""
+    import time
+    e = _env(); e["NEUTFEM_INJECT_FAIL"] = inject; e["NEUTFEM_COMM_TIMEOUT_S"] = "60"
+    t0 = time.time()
+    bad, logs = _run_ranks(3, [str(tmp_path / "none.npz"), 1, use_diag, 16, 0, 0, 8], tmp_path, timeout=100, env=e, wait_all=True)   # 8 fine outers (4 coarse)
+    assert bad == "a rank failed", (bad, logs)                     # not "timed out": every rank ended by itself
+    assert time.time() - t0 < 60, logs                             # and long before the collective timeout
+    per = logs.split("--- rank ")[1:]
+    assert len(per) == 3 and all("(rc=0)" not in p.splitlines()[0] for p in per), logs
+    assert "injected failure on rank 1" in per[1], logs
+    for p in (per[0], per[2]):
+        assert "another rank of the team reported an error" in p and expect in p, logs
+
+
+def test_a_lost_peer_times_out_and_the_solver_can_be_closed(tmp_path):
+    """after NF_ERR_COMM the streams hold collectives whose peer is gone; nf_destroy used to synchronise them (and the coarse
+    twin kept the aborted communicator), so closing the solver could block for ever.  Rank 1 of 2 exits before the solve: rank 0's
+    first collective times out (NEUTFEM_COMM_TIMEOUT_S = 5), the team is marked dead, a second solve is refused at once and close()
+    returns without waiting for the device."""
+    import time
+    e = _env(); e["NEUTFEM_WORKER_LOSE_RANK"] = "1"; e["NEUTFEM_COMM_TIMEOUT_S"] = "5"
+    t0 = time.time()
+    bad, logs = _run_ranks(2, [str(tmp_path / "none.npz"), 1, 0, 16], tmp_path, timeout=90, env=e, wait_all=True)
+    assert bad == "a rank failed" and time.time() - t0 < 60, (bad, logs)
+    r0 = logs.split("--- rank ")[1]
+    assert "(rc=5)" in r0.splitlines()[0], logs
+    assert "did not complete within 5 s" in r0 and "second solve refused" in r0 and "is unusable" in r0, logs
+    assert float(r0.split("closed in ")[1].split()[0]) < 2.0, logs
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -89,15 +89,17 @@ def test_full_size_256cube_properties():
     phi = s.get_phi()
     assert np.isfinite(phi).all() and abs(np.linalg.norm(phi) - 1.0) < 1e-12          # normalised iterate (:1780-1784)
     s.close()
-    # the same operator cut into two z-slabs (partition method, loopback on this GPU)
-    t = HipTeam(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], case["z_breaks"], [(0, 128), (128, 256)])
-    t.set_linear_solver(6)
-    for a_, ty in case["bc"]:
-        t.set_bc(a_, ty)
-    t.upload_xs_global(case["D"], case["SigR"], case["NSF"], case["Chi"], case["SigS"]); t.build()
-    yt = t.schur_apply(1, x.reshape(256, 256, 256))
-    assert rel_l2(yt.ravel(), Sx) < 1e-12                         # Sx = group 1 from the loop above
-    t.close()
+    # the same operator in BASELINE config 3's own layout: 8 z-slabs of 32 planes (partition method, loopback on this GPU; slabs of 32
+    # planes take the single-exchange path: separator coupling 0.268^32), and cut into two slabs of 128
+    for planes in ([(32 * i, 32 * i + 32) for i in range(8)], [(0, 128), (128, 256)]):
+        t = HipTeam(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], case["z_breaks"], planes)
+        t.set_linear_solver(6)
+        for a_, ty in case["bc"]:
+            t.set_bc(a_, ty)
+        t.upload_xs_global(case["D"], case["SigR"], case["NSF"], case["Chi"], case["SigS"]); t.build()
+        yt = t.schur_apply(1, x.reshape(256, 256, 256))
+        assert rel_l2(yt.ravel(), Sx) < 1e-12, len(planes)        # Sx = group 1 from the loop above
+        t.close()
 
 
 @pytest.mark.parametrize("name", ["iaea2d", "iaea3d_1x1", "zion2d"])
@@ -328,7 +330,7 @@ def test_solve_adjoint(name, rt):
     s.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "plain_loads_split_dot"])
+@pytest.mark.parametrize("variant", ["default", "plain_loads_split_dot", "c3_layout_8_slabs_of_32_planes", "c3_layout_two_reductions"])
 def test_iaea3d_256cube_golden(variant):
     """The HEADLINE workload at its own size (IAEA-3D resampled to 256^3, 16.8 M cells, 2 groups: what bench.py times) against the
     oracle's golden run (tests/golden/make_golden_256cube.py, about an hour of one core): 2 outer iterations from the flat flux with
@@ -336,24 +338,43 @@ def test_iaea3d_256cube_golden(variant):
     k-history is compared at 2e-9 and the flux at 1e-8, per group and overall (src/NeutFEM.cpp:1694-1802, src/solvers.cpp:577-636).
       default                 the kernels and options the bench runs: streaming loads, the whole p.q summed in the last pass
       plain_loads_split_dot   the same passes with plain loads and per-pass shares of p.q (z.w form in the y / z passes: what the
-                              chunked long-line passes of 512-cell meshes need)"""
+                              chunked long-line passes of 512-cell meshes need)
+      c3_layout_8_slabs_of_32_planes   BASELINE config 3 AS IT IS DECOMPOSED on 8 GPUs -- 8 z-slabs of 256 x 256 x 32 (here in one process:
+                              interface planes by device copy, everything else as on ranks): partition-method z lines, slab passes,
+                              x || y, and the teams' default CG with ONE reduction per iteration (Cg1)
+      c3_layout_two_reductions         the same team with the reference recurrence (two reductions per iteration)"""
     import json
     from bench import make_solver
     from neutfem_amd import cases
+    from neutfem_amd.capi import HipTeam
     with open(os.path.join(os.path.dirname(__file__), "golden", "golden_iaea3d_256cube.json")) as f:
         r = json.load(f)["runs"]["fixed"]
-    s = make_solver(cases.iaea3d_resampled(256), 0)
-    if variant != "default":
+    case = cases.iaea3d_resampled(256)
+    team = variant.startswith("c3_layout")
+    if team:
+        s = HipTeam(0, 0, case["ng"], case["x_breaks"], case["y_breaks"], case["z_breaks"], [(32 * i, 32 * i + 32) for i in range(8)])
+        s.set_linear_solver(6)
+        for a_, ty in case["bc"]:
+            s.set_bc(a_, ty)
+        s.upload_xs_global(case["D"], case["SigR"], case["NSF"], case["Chi"], case["SigS"]); s.build()
+        s.head.set_option("cg_single_reduce", 0 if variant.endswith("two_reductions") else 1)
+    else:
+        s = make_solver(case, 0)
+    if variant == "plain_loads_split_dot":
         s.set_option("nt_loads", 0); s.set_option("split_dot", 2)
     s.set_tol(*r["tol"])
     k, n = s.solve_keff()
     h = s.history()
-    assert n == r["n_outer"] == 2 and s.info("last_path") == 0                   # host-driven classic path: k_schur_x / k_schur_s + k_cg_* (the bench's kernels)
+    assert n == r["n_outer"] == 2
+    if team:
+        assert s.head.info("cg_reductions") == (2 if variant.endswith("two_reductions") else 1) and s.head.info("n_local_slabs") == 8
+    else:
+        assert s.info("last_path") == 0                                          # host-driven classic path: k_schur_x / k_schur_s + k_cg_* (the bench's kernels)
     np.testing.assert_allclose(h["k"], r["k_hist"], rtol=2e-9)
     assert abs(k - r["keff"]) / r["keff"] < 2e-9
     cg_g, cg_o = h["cg"].sum(), np.sum(r["cg"])
     assert abs(cg_g - cg_o) <= 0.3 * cg_o, (cg_g, cg_o)                          # void cells: CG counts are rounding-sensitive on either side (measured 2574 vs 3163)
-    phi = s.get_phi().ravel()
+    phi = (s.get_phi_local() if team else s.get_phi()).ravel()                 # (ng, planes, ny, nx) either way
     smp, ref = phi[::r["phi_stride"]], np.array(r["phi_samples"])
     d = rel_l2(smp, ref)
     per = phi.size // 2; cut = (per + r["phi_stride"] - 1) // r["phi_stride"]      # samples [0, cut) belong to group 0

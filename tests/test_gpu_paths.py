@@ -29,6 +29,10 @@ PATHS = [("classic", dict(resident=0, cg_fuse3=0), 0), ("fuse3", dict(resident=0
          ("classic-no-host-page", dict(resident=0, cg_fuse3=0, host_pub=0), 0)]
 
 
+# paths that run the SAME arithmetic as another one (other load instructions, another readback route, a refused XCD launch falling back)
+BITWISE_TWINS = {"classic-streaming": "classic", "classic-no-host-page": "classic", "xcd-refused": "fuse3"}
+
+
 def _run(inp, rt, p, tol, opts, coarse=False, factors=()):
     s = make_hip(inp, rt, p); s.set_tol(*tol)
     for k, v in opts.items():
@@ -68,6 +72,8 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
             continue                                                # split dot / chunked lines exist for RT0-P0 y / z passes only: elsewhere these options change nothing
         if shape[0] * shape[1] * shape[2] > 3000 and name in ("resident-one-sided", "big-whole-dot", "big-split-dot"):
             continue                                                # the largest shape (a minute of solves): these three differ from a neighbour by one switch that 16 smaller shapes cover
+        if shape[0] * shape[1] * shape[2] > 1000 and name in BITWISE_TWINS:
+            continue                                                # asserted bit-identical to their twin below on the eleven smaller shapes: converging them again on the big ones adds run time, not coverage
         r = res[name] = _run(inp, rt, p, tol, opts)
         if name == "resident-scans" and shape[0] > 128:
             path = 0                                                # the scan variant takes x lines of at most 128 cells (one chunk per line)
@@ -78,9 +84,9 @@ def test_paths_agree_at_tight_tolerance(shape, rt, p, ng):
         assert abs(r["k"] - ko) / ko < 1e-9, (name, r["k"], ko)
         assert rel_l2(r["phi"].ravel(), o.phi_dofs().ravel()) < 1e-8, name
         assert rel_l2(r["J"].ravel(), o.J_dofs().ravel()) < 1e-7, name
-    assert res["classic-streaming"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-streaming"]["phi"], res["classic"]["phi"])   # same arithmetic, other load instructions
-    assert res["classic-no-host-page"]["k"] == res["classic"]["k"] and np.array_equal(res["classic-no-host-page"]["phi"], res["classic"]["phi"])   # readback route only
-    assert res["xcd-refused"]["k"] == res["fuse3"]["k"] and np.array_equal(res["xcd-refused"]["phi"], res["fuse3"]["phi"])   # the fall-back IS the launch path
+    for twin, base in BITWISE_TWINS.items():
+        if twin in res:
+            assert res[twin]["k"] == res[base]["k"] and np.array_equal(res[twin]["phi"], res[base]["phi"]), twin
     for name in ("fuse3", "xcd", "xcd-keff", "resident", "resident-scans", "resident-one-sided", "big-split-dot", "big-whole-dot", "big-chunked-lines"):
         if name not in res:
             continue

@@ -49,10 +49,10 @@ def test_thin_slabs_use_separator_sweeps(planes):
     for g in range(2):
         x = rng.standard_normal((30, 8, 9))
         assert rel_l2(t.schur_apply(g, x).ravel(), o.schur_apply(g, x.ravel())) < 1e-12
-    tol = (1e-12, 1e-10, 1e-10, 40, 2000)                          # fixed work: 40 outers with tight inner solves
+    tol = (1e-12, 1e-10, 1e-10, 20, 2000)                          # fixed work: 20 outers with tight inner solves
     o.set_tol(*tol); t.set_tol(*tol)
     ko = o.SolveKeff(); kt, n = t.solve_keff()
-    assert n == o.info("last_outer") == 40 and abs(kt - ko) / ko < 1e-9
+    assert n == o.info("last_outer") == 20 and abs(kt - ko) / ko < 1e-9
     assert rel_l2(t.get_phi_local().ravel(), o.phi_dofs().reshape(2, 30, 8, 9).ravel()) < 1e-8
     t.close()
 
@@ -81,10 +81,12 @@ def test_team_solve_keff_matches_undivided_and_oracle(planes):
     hs, ht = s.history()["cg"][:min(ns, nt)], t.history()["cg"][:min(ns, nt)]
     assert np.abs(ht - hs).max() <= 0.02 * hs.max()
     # the big-mesh instantiations of the passes (non-temporal loads; on by themselves beyond 8 M cells per slab): same arithmetic, same bits
+    fixed = (0.0, 1e-10, 1e-10, 6, 2000)                           # bit-identity shows after any number of outers: six, not the whole convergence again
+    t.set_tol(*fixed); t.reset_flux(); k1, n1 = t.solve_keff(); phi_1 = t.get_phi_local().ravel()
     for x in t.slabs:
         x.set_option("nt_min_cells", 0)
     t.reset_flux(); k2, n2 = t.solve_keff()
-    assert k2 == kt and n2 == nt and np.array_equal(t.get_phi_local().ravel(), phi_t)
+    assert k2 == k1 and n2 == n1 == 6 and np.array_equal(t.get_phi_local().ravel(), phi_1)
     s.close(); t.close()
 
 
