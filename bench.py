@@ -157,6 +157,35 @@ def small_configs(device):
     return res
 
 
+def higher_order_throughput(device, n=128, rt=1):
+    """A throughput number for the higher orders at a size where the chip is busy (KOEBERG's 1 156 cells only show
+    latency): one Schur apply y = S_0 x of IAEA-3D resampled to n^3 with RT1-P1, timed back to back with HIP events (nf_time_schur_apply),
+    in algorithmic bytes by SURVEY 8(d)'s rule for RT1+ / P1+: 24 n_phi + 40 n_J with the bubble DOFs in n_J (3D RT1: 4 DOFs per face,
+    4 interior per cell and direction; P1: 8 moments per cell) -- 1 148 B per cell.  What the kernels really move is less: the line
+    factors are shared by the transverse modes and the bubbles are condensed per cell, so this figure can exceed what
+    the same bytes would give on a kernel that stored a factor per face DOF."""
+    from neutfem_amd import cases
+    from neutfem_amd.capi import HipSolver
+    c = cases.iaea3d_resampled(n)
+    s = HipSolver(rt, rt, c["ng"], c["x_breaks"], c["y_breaks"], c["z_breaks"], device)
+    s.set_linear_solver(6)
+    for at, ty in c["bc"]:
+        s.set_bc(at, ty)
+    s.upload_xs(c["D"], c["SigR"], c["NSF"], c["Chi"], c["SigS"]); s.build()
+    ms = s.time_schur_apply(0, 20)
+    per_dir = {}
+    for nm in ("schur_x", "schur_y", "schur_z"):
+        cnt, tot = s.profile(nm)
+        if cnt:
+            per_dir[nm] = round(tot / cnt, 4)
+    alg = 24.0 * s.n_phi + 40.0 * s.n_J
+    res = dict(workload=f"IAEA-3D resampled {n}^3 RT{rt}-P{rt}, one Schur apply of group 0", cells=int(s.ne), n_phi=int(s.n_phi), n_J=int(s.n_J),
+               apply_ms=round(ms, 4), pass_ms=per_dir, alg_bytes=alg, alg_bytes_per_cell=round(alg / s.ne, 1), achieved_GBps=round(alg / (ms * 1e-3) / 1e9, 1),
+               frac_of_8TBps=round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    s.close()
+    return res
+
+
 def split_planes(nz, parts):
     """contiguous z-plane ranges, as even as possible"""
     cuts = [round(i * nz / parts) for i in range(parts + 1)]
@@ -435,6 +464,12 @@ def main():
     if rank == 0 and slabs_total == 1 and not a.no_small:
         note("small BASELINE configs")
         out["other_configs"] = small_configs(local)
+    if rank == 0 and slabs_total == 1 and not a.no_small and a.case == "iaea3d":
+        note("higher-order throughput (RT1-P1 Schur apply at 128^3)")
+        try:
+            out["higher_order"] = higher_order_throughput(local)
+        except Exception as e:                                       # an extra must never cost the headline line
+            out["higher_order"] = dict(error=str(e)[:300])
     if rank == 0 and slabs_total == 1:
         # ---- CPU baseline: bounded sample of the same workload on the host (1 core) -------------------------------
         if a.cpu_sample_iters > 0:

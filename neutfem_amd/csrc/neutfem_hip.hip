@@ -1245,7 +1245,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
         }
     }
     // 8-cell segments up to 1024 cells per line (16 / 32 cells spill to scratch: 1.4x slower even though TX drops to 8 at 1024)
-    int SEG = T->opt_s_seg ? T->opt_s_seg : (S->nb > 0 ? (n <= 256 ? 4 : 8) : (n <= 1024 ? 8 : (n <= 2048 ? 16 : 32)));
+    // higher orders: 4-cell segments up to 256 cells per line; beyond, RT1 keeps 8 (148 B / lane of scratch and still faster: y 97 vs 122 us on
+    // 48 x 512 x 48), RT2 takes 4 up to 512 cells (8 columns per block, no scratch: y 352 vs 383 us, z 412 vs 431; profiles/r04_g_higher_orders.txt)
+    int SEG = T->opt_s_seg ? T->opt_s_seg : (S->nb > 0 ? ((n <= 256 || (S->nb == 2 && n <= 512)) ? 4 : 8) : (n <= 1024 ? 8 : (n <= 2048 ? 16 : 32)));
     int NSEG = (n + SEG - 1) / SEG;
     if (NSEG > 128) return fail(NF_ERR_UNSUPPORTED, "line length %d exceeds the segmented kernel limit", n);
     int TX = T->opt_s_tx ? T->opt_s_tx : 64;
@@ -1667,11 +1669,17 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         NFCHK(launch_cg_xcd(S0, g, f3, x[0], seq));
         NFCHK(pub_wait(T, seq, &sc, nullptr, 0));
         if (sc.err == 4) {
-            T->opt_cgx = 0;
-            return fail(NF_ERR_HIP, "XCD-local CG (k_cg_xcd): a grid barrier timed out in the middle of the solve of group %d (a participant was lost); "
-                                    "the path is now off for this solver", g);
+            // a grid barrier timed out in the middle of the solve (a participant stalled for longer than the bound: another process on
+            // the GPU, a debugger): x, r and p are half-way, but the right-hand side is intact -- start the solve again on the launch
+            // path (the kernels have all left by now: the flag that ended one ended the others) and keep this solver off the one-XCD path
+            T->opt_cgx = 0; ++T->xcd_refused;
+            HIPCHK(hipStreamSynchronize(T->stream));
+            for (int i = 0; i < ns; ++i) {
+                nf_solver *S = T->slabs[i];
+                hipLaunchKernelGGL(k_cg_init, dim3(gcnt[i]), dim3(256), 0, T->stream, rhs[i], x[i], S->d_r, S->d_p, S->nphi, T->d_partials + i * T->slab_cap);
+            }
         }
-        if (sc.err != 3) {
+        if (sc.err != 3 && sc.err != 4) {
             T->last_xcd = 1; ++T->xcd_solves;
             HIPCHK(hipGetLastError());
             if (!std::isfinite(sc.rr)) return fail(NF_ERR_NUMERIC, "CG produced a non-finite residual (group %d)", g);
@@ -1682,7 +1690,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
         }
         // the workgroups did not assemble (nothing placed on the XCD, or it is busy): no vector has been touched -- this solve and the
         // following ones of this solver go through the launch path
-        T->opt_cgx = 0; ++T->xcd_refused;
+        if (sc.err == 3) { T->opt_cgx = 0; ++T->xcd_refused; }
         for (int i = 0; i < ns; ++i) T->slabs[i]->fuse = fused ? CgFuse{ T->slabs[i]->d_p, T->slabs[i]->d_r, x[i] } : CgFuse{ nullptr, nullptr, nullptr };
         NFCHK(team_finalize(T, FIN_RHS, gcnt, 1, T->d_out, tol, maxit));
         memset(&sc, 0, sizeof sc);
@@ -3279,16 +3287,21 @@ int nf_time_device_copy(nf_handle S, size_t bytes, int reps, double *gbps)
     double best = 0.0; hipError_t e = hipSuccess;
     int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, S->device);
     const bool verbose = getenv("NEUTFEM_COPY_VERBOSE") != nullptr;
-    // best of: plain / non-temporal copy kernels with 4 or 8 16-byte loads in flight per lane at 8, 16, 32 and 64 blocks per CU, and the
-    // runtime's own device-to-device copy
-    const int NV = 17;
+    // best of: plain / non-temporal copy kernels with 4 (or 8) 16-byte loads in flight per lane at 16 ... 256 blocks per CU or one chunk
+    // per block, and the runtime's own device-to-device copy (measured on one box, GB/s: 16 per CU 5424 / 5249 nt, 64 per CU 5622 / 5886 nt,
+    // 8 in flight 5344 - 5638, hipMemcpyDtoD 4778; round 3's kernel with 8-byte halves: 4790)
+    struct V { int kind, per_cu; };                               // kind 0 plain x4, 1 nt x4, 2 nt x8, 3 hipMemcpy ; per_cu 0 = one chunk per block
+    const V vs[] = { {0, 16}, {0, 64}, {0, 256}, {0, 0}, {1, 16}, {1, 64}, {1, 256}, {1, 0}, {2, 64}, {2, 0}, {3, 0} };
+    const int NV = (int)(sizeof vs / sizeof vs[0]);
     for (int variant = 0; variant < NV && e == hipSuccess; ++variant) {
+        const V v = vs[variant];
+        const int U = v.kind == 2 ? 8 : 4;
+        const long full = (n2 + 256L * U - 1) / (256L * U);
+        const int grid = (int)std::min<long>(v.per_cu ? (long)ncu * v.per_cu : full, full);
         auto once = [&]() {
-            if (variant == NV - 1) { (void)hipMemcpyAsync(b, a, (size_t)n2 * 16, hipMemcpyDeviceToDevice, st); return; }
-            const int grid = ncu * (8 << (variant % 4)); const int kind = variant / 4;
-            if (kind == 0) hipLaunchKernelGGL((k_copy<false, 4>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
-            else if (kind == 1) hipLaunchKernelGGL((k_copy<false, 8>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
-            else if (kind == 2) hipLaunchKernelGGL((k_copy<true, 4>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
+            if (v.kind == 3) { (void)hipMemcpyAsync(b, a, (size_t)n2 * 16, hipMemcpyDeviceToDevice, st); return; }
+            if (v.kind == 0) hipLaunchKernelGGL((k_copy<false, 4>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
+            else if (v.kind == 1) hipLaunchKernelGGL((k_copy<true, 4>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
             else hipLaunchKernelGGL((k_copy<true, 8>), dim3(grid), dim3(256), 0, st, (const nf_d2 *)a, b, n2);
         };
         once();
@@ -3298,9 +3311,8 @@ int nf_time_device_copy(nf_handle S, size_t bytes, int reps, double *gbps)
         e = hipEventSynchronize(e1);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
         const double gb = ms > 0.f ? 2.0 * (double)n2 * 16.0 * reps / (ms * 1e-3) / 1e9 : 0.0;   // read + write
-        if (verbose) fprintf(stderr, "[copy] variant %2d (%s, %d blocks per CU): %.0f GB/s\n", variant,
-                             variant == NV - 1 ? "hipMemcpyDtoD" : variant / 4 == 0 ? "plain, 4 in flight" : variant / 4 == 1 ? "plain, 8 in flight" : variant / 4 == 2 ? "nt, 4 in flight" : "nt, 8 in flight",
-                             variant == NV - 1 ? 0 : (8 << (variant % 4)), gb);
+        if (verbose) fprintf(stderr, "[copy] variant %2d (%s, grid %d): %.0f GB/s\n", variant,
+                             v.kind == 3 ? "hipMemcpyDtoD" : v.kind == 0 ? "plain, 4 in flight" : v.kind == 1 ? "nt, 4 in flight" : "nt, 8 in flight", v.kind == 3 ? 0 : grid, gb);
         if (e == hipSuccess) best = std::max(best, gb);
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

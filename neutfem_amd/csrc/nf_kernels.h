@@ -689,6 +689,15 @@ __device__ __forceinline__ void ld2(const double *p, long i, bool ok, bool vec, 
 // non-temporal *stores* lose (5.00 / 4.88 alone, 5.40 / 5.54 combined).  Not for meshes that live in the caches between launches.
 template <bool NT>
 __device__ __forceinline__ double ldg(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+// wave-uniform array base + 32-bit byte offset: ONE VGPR addresses the same cell in every array of a pass (global_load v, v_off, s[base])
+// instead of a 64-bit address per array and cell -- what keeps the many-array passes (chunked long lines; RT1 / RT2 y and z passes) out of
+// scratch.  The host takes such a kernel only while one group's array stays below 4 GiB.
+template <bool NT> __device__ __forceinline__ double ldo(const double *p, unsigned byte_off)
+{
+    const double *q = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + byte_off);
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+__device__ __forceinline__ void sto(double *p, unsigned byte_off, double v) { *reinterpret_cast<double *>(reinterpret_cast<char *>(p) + byte_off) = v; }
 
 // Fused CG (undivided mesh, any order: the x pass with all its transverse modes touches every moment exactly once): the
 // vector updates that follow FIN_RR -- x_sol += alpha p and p = r + beta p
@@ -1026,6 +1035,10 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     // trip per cell instead of one per phase (measured with in-kernel stamps: 9.6 k cycles for the 36 loads of a fused y / z block).
     if (SLAB && !SF) fuse = false;
     const bool fr = SLAB ? fuse : fro;                           // the input vector is r + beta x (wave-uniform)
+    // higher-order passes of undivided meshes touch up to eleven arrays per cell: 32-bit byte offsets from the wave-uniform bases (ldo / sto)
+    constexpr bool O32 = NB > 0 && !SLAB;
+    const unsigned ob8 = (unsigned)(base * 8), sl8 = (unsigned)(sl * 8);
+#define NF_A8(c) (ob8 + (unsigned)(c) * sl8)
     double rv[(SLAB && !SF) ? 1 : SEG + 1], sv[(SLAB && SF) ? SEG : 1];   // r of the same cells; slab fuse: x_sol of the owned cells
     double qv[(SR && SF) ? SEG + 1 : 1], rq_[(SR && !SF) ? SEG : 1];      // SR: q of the same cells (endpoint pass); r of the owned cells (accumulation pass)
     double srr = 0.0, sqq = 0.0, srq = 0.0;
@@ -1035,13 +1048,23 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
         const int c = c0 + i; const bool ok = valid && c < n;
         const long a = base + (long)c * sl;
         // the overlap cell (i == SEG) is the next segment's first: keep that line for it (see k_schur_c on why this is not a ternary on i)
-        if (i < SEG || XC) xv[i] = ok ? ldg<NT>(x + a) : 0.0; else xv[i] = ok ? x[a] : 0.0;
-        if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : ldg<NT>(x + a + roff)) : 0.0;
+        if (O32) xv[i] = ok ? ldo<NT>(x, NF_A8(c)) : 0.0;
+        else if (i < SEG || XC) xv[i] = ok ? ldg<NT>(x + a) : 0.0; else xv[i] = ok ? x[a] : 0.0;
+        if (!SLAB || SF) rv[(SLAB && !SF) ? 0 : i] = (fr && ok) ? (SLAB ? fz.r[a] : (O32 ? ldo<NT>(x + roff, NF_A8(c)) : ldg<NT>(x + a + roff))) : 0.0;
         if (SLAB && SF && i < SEG) sv[(SLAB && SF) ? i : 0] = (fuse && ok) ? fz.xsol[a] : 0.0;
         if (SR && SF) qv[(SR && SF) ? i : 0] = (fuse && ok) ? sa.sr_q[a] : 0.0;
-        if (i < SEG) Lv[i] = ok ? ldg<NT>(L + a) : 0.0; else Lv[i] = ok ? L[a] : 0.0;
-        if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
-        if (NB > 0) {
+        if (O32) { Lv[i] = ok ? ldo<NT>(L, NF_A8(c)) : 0.0; if (i < SEG) Rv[i] = ok ? ldo<NT>(DR, NF_A8(c)) : 0.0; }
+        else {
+            if (i < SEG) Lv[i] = ok ? ldg<NT>(L + a) : 0.0; else Lv[i] = ok ? L[a] : 0.0;
+            if (i < SEG) Rv[i] = ok ? ldg<NT>(DR + a) : 0.0;
+        }
+        if (NB > 0 && O32) {
+            v1a[i] = ok ? ldo<XC>(ma.x[1], NF_A8(c)) : 0.0;
+            if (NB > 1) v2a[NB > 1 ? i : 0] = ok ? ldo<XC>(ma.x[2], NF_A8(c)) : 0.0;
+            r1[i] = (fro && ok) ? ldo<XC>(ma.x[1] + roff, NF_A8(c)) : 0.0;
+            if (NB > 1) r2[NB > 1 ? i : 0] = (fro && ok) ? ldo<XC>(ma.x[2] + roff, NF_A8(c)) : 0.0;
+            if (i < SEG) Dv[i] = ok ? ldo<false>(ma.D, NF_A8(c)) : 0.0;
+        } else if (NB > 0) {
             v1a[i] = ok ? ldg<XC>(ma.x[1] + a) : 0.0;
             if (NB > 1) v2a[NB > 1 ? i : 0] = ok ? ldg<XC>(ma.x[2] + a) : 0.0;
             r1[i] = (!SLAB && fro && ok) ? ldg<XC>(ma.x[1] + a + roff) : 0.0;
@@ -1159,7 +1182,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 #pragma unroll
     for (int i = 0; i < SEG; ++i) {
         const int c = c0 + i; const bool ok = acc && valid && c < n && wr;
-        yo[i] = ok ? ldg<NT>(y + base + (long)c * sl) : 0.0;
+        yo[i] = ok ? (O32 ? ldo<NT>(y, NF_A8(c)) : ldg<NT>(y + base + (long)c * sl)) : 0.0;
         if (SLAB && NB == 0 && sa.yadd) yo[i] += ok ? sa.yadd[base + (long)c * sl] : 0.0;     // same order on every cell: (y_x + y_y) + z part
     }
     double y1o[NB > 0 ? SEG : 1], y2o[NB > 1 ? SEG : 1];
@@ -1167,8 +1190,8 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
 #pragma unroll
         for (int i = 0; i < SEG; ++i) {
             const bool okl = acc && valid && c0 + i < n && wr; const long a = base + (long)(c0 + i) * sl;
-            y1o[i] = okl ? ma.y[1][a] : 0.0;
-            if (NB > 1) y2o[NB > 1 ? i : 0] = okl ? ma.y[2][a] : 0.0;
+            y1o[i] = okl ? (O32 ? ldo<false>(ma.y[1], NF_A8(c0 + i)) : ma.y[1][a]) : 0.0;
+            if (NB > 1) y2o[NB > 1 ? i : 0] = okl ? (O32 ? ldo<false>(ma.y[2], NF_A8(c0 + i)) : ma.y[2][a]) : 0.0;
         }
     }
     NF_STAMP(stamp, 6);
@@ -1223,9 +1246,14 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
             const int c = c0 + i;
             if (valid && c < n) {
                 const long a = base + (long)c * sl;
-                y[a] = yo[i];
-                if (NB > 0) ma.y[1][a] = y1o[i];
-                if (NB > 1) ma.y[2][a] = y2o[NB > 1 ? i : 0];
+                if (O32) {
+                    sto(y, NF_A8(c), yo[i]); sto(ma.y[1], NF_A8(c), y1o[i]);
+                    if (NB > 1) sto(ma.y[2], NF_A8(c), y2o[NB > 1 ? i : 0]);
+                } else {
+                    y[a] = yo[i];
+                    if (NB > 0) ma.y[1][a] = y1o[i];
+                    if (NB > 1) ma.y[2][a] = y2o[NB > 1 ? i : 0];
+                }
             }
         }
     }
@@ -1325,6 +1353,7 @@ __device__ __forceinline__ double schur_s_tile(const ModeArgs &ma, const Geom &G
     if (SR && SF) return srr;                                    // endpoint pass: this thread's share of |r|^2
     if (SR && extra) { extra[0] = sqq; extra[1] = srq; }
     return dot;
+#undef NF_A8
 }
 
 // Slab variants keep r and x_sol of their cells in registers next to x, L, 1/d (loads first, see schur_s_tile): blocks of at most 512
@@ -1391,11 +1420,6 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? (SR ?
 // LDS (doubles): sA, sB [NS TX] (forward and backward summaries in turn), sC, sL1 [TX], 16 of reduction scratch, pW, pL [CH TX], pZ [NS TX].
 // Per cell the same expressions as k_schur_s (the value crossing the chunk boundary is the swept one, not a composed summary:
 // the two kernels agree to rounding, not bitwise).
-template <bool NT> __device__ __forceinline__ double ldo(const double *p, unsigned byte_off)     // uniform base + 32-bit byte offset: one VGPR per address
-{
-    const double *q = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + byte_off);
-    return NT ? __builtin_nontemporal_load(q) : *q;
-}
 // Addresses are 32-bit BYTE offsets from the (wave-uniform) array bases -- the host takes this kernel only while one group's array is
 // below 4 GiB.  One VGPR per cell address, shared by x, L, 1/d and y, instead of a 64-bit pair per array: that is what keeps the
 // two-chunk body inside the 128 registers of a 1024-thread block (with 64-bit addresses it spilled 10-12 registers to scratch,
@@ -1657,7 +1681,7 @@ __global__ __launch_bounds__(256) void k_cg_rupdate3(double *__restrict__ r, con
 // Partial sums: one per workgroup, added by wave_sum's fixed tree over the workgroups -- not the order of the launch path, so the iterates differ from it in
 // the last bits (like the resident kernel's do); every run gives the same bits.
 struct ResidentOut { double keff; int n_outer, status, cg_total, pad; };   // status 0 ok, 2 diverged (non-finite k or dphi); k_keff_xcd: 3 not assembled, 4 barrier timeout
-struct XcdState { unsigned arrived, nreg, count, timeout; };
+struct XcdState { unsigned arrived, nreg, count, timeout, go; };   // go: 0 undecided, 1 start (every workgroup has registered), 2 do not start
 struct XcdArgs {
     ModeArgs ma[3]; Geom G;
     const double *L[3], *DR[3], *D0[3];
@@ -1670,11 +1694,18 @@ struct XcdArgs {
     XcdState *st; HostPub *hp; unsigned long long seq; int xcc;
 };
 __device__ __forceinline__ unsigned xld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// bounded by wall time (s_memrealtime: 100 MHz, independent of the shader clock), not by an iteration count: 0.5 s -- only a lost
+// participant gets there; a workgroup that was merely preempted for a few milliseconds does not fail the solve
+constexpr unsigned long long XCD_SPIN_TICKS = 50000000ull;
 __device__ __forceinline__ bool xcd_spin(const unsigned *p, unsigned target, unsigned *timeout)
 {
-    for (int i = 0; i < 400000; ++i) {                           // ~0.3 s: only a lost participant gets here
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0;; ++i) {
         if (xld(p) >= target) return true;
-        if ((i & 1023) == 1023 && xld(timeout)) return false;
+        if ((i & 1023) == 1023) {
+            if (xld(timeout)) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > XCD_SPIN_TICKS) break;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
     __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1708,13 +1739,25 @@ __device__ __forceinline__ bool xcd_assemble(XcdState *st, int xcc, int *s_i, Xc
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
     const bool part = (int)(id & 0xf) == xcc;
     *none = false;
+    // The decision to start is ONE word that every participant reads (with a bounded spin per workgroup, one could time out
+    // while another had just seen everybody arrive, and the two disagreed): the last workgroup of the grid to arrive -- every registration
+    // is in by then -- writes go = 1 (or 2: nobody or too many registered); a participant whose wait expires tries to write 2; whoever
+    // writes first decides for all.
     if (threadIdx.x == 0) {
         s_i[0] = part ? (int)__hip_atomic_fetch_add(&st->nreg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
         const unsigned before = __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *none = before + 1 == gridDim.x && xld(&st->nreg) == 0;
+        if (before + 1 == gridDim.x) {
+            const unsigned n = xld(&st->nreg);
+            *none = n == 0;
+            unsigned expect = 0u;
+            (void)__hip_atomic_compare_exchange_strong(&st->go, &expect, (n > 0 && n <= 64) ? 1u : 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (!part) return false;
-    if (threadIdx.x == 0) { s_i[2] = xcd_spin(&st->arrived, gridDim.x, &st->timeout) ? 1 : 0; s_i[1] = (int)xld(&st->nreg); }
+    if (threadIdx.x == 0) {
+        if (!xcd_spin(&st->go, 1u, &st->timeout)) { unsigned expect = 0u; (void)__hip_atomic_compare_exchange_strong(&st->go, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        s_i[2] = xld(&st->go) == 1u ? 1 : 0; s_i[1] = (int)xld(&st->nreg);
+    }
     __syncthreads();
     C.widx = s_i[0]; C.P = s_i[1]; C.ok = s_i[2] != 0 && C.P <= 64;
     C.nbar = 0; C.nred = 0;

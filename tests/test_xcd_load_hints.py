@@ -22,7 +22,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(ROOT, "neutfem_amd", "lib", "libneutfem_hip.so")
 
 # plain (hint-less) global loads per instantiation <NCH, VEC, NB, SEG>, by kernel and NB, as built from the reviewed sources of round 4
-PLAIN_MAX = {("k_cg_xcd", 0): 22, ("k_cg_xcd", 1): 72, ("k_cg_xcd", 2): 74, ("k_keff_xcd", 0): 12, ("k_keff_xcd", 1): 62, ("k_keff_xcd", 2): 64}
+PLAIN_MAX = {("k_cg_xcd", 0): 22, ("k_cg_xcd", 1): 70, ("k_cg_xcd", 2): 72, ("k_keff_xcd", 0): 12, ("k_keff_xcd", 1): 60, ("k_keff_xcd", 2): 62}
 
 
 def _disassemble(tmp):
@@ -48,9 +48,10 @@ def test_exchanged_vector_loads_of_the_xcd_kernels_keep_their_cache_bypass(tmp_p
         assert t, name
         loads = [l for l in f.splitlines() if re.search(r"\bglobal_load", l)]
         plain = [l for l in loads if not re.search(r"\b(nt|sc0|sc1)\b", l.split("//")[0])]
+        nt = [l for l in loads if re.search(r"\bnt\b", l.split("//")[0])]
         key = (t.group(1), int(t.group(4)))
         seen[t.group(0)] = (len(loads), len(plain))
-        assert len(loads) - len(plain) >= 80, (name, len(loads), len(plain))          # the exchanged vectors ARE read with the hint
+        assert len(nt) >= 40, (name, len(loads), len(nt), len(plain))                   # the exchanged vectors ARE read with the hint (the sc1 loads are the barrier's own polls)
         assert len(plain) <= PLAIN_MAX[key], f"{name}: {len(plain)} global loads without nt/sc0/sc1 (reviewed maximum {PLAIN_MAX[key]}): a load of a vector that " \
                                              f"other workgroups write during the launch may have lost its L1 bypass -- read the disassembly before raising the bound"
     assert len(seen) == 24, sorted(seen)                             # 12 instantiations of each kernel: none went missing from the check
