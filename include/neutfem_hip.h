@@ -74,7 +74,8 @@ int nf_comm_selftest(nf_handle h);
 int nf_team_schur_apply(nf_handle h, int g, const double *const *x_dev, double *const *y_dev);
 
 /* sizes: "dim","nx","ny","nz","ne","ng","n_phi","n_J","n_loc","last_outer","last_cg_total",
- * "coarse_outer","device","n_local_slabs","n_ranks","rank" ; returns -1 for an unknown key */
+ * "coarse_outer","device","n_local_slabs","n_ranks","rank","cg_reductions" (cross-rank reductions per CG iteration of the last CG solve on a
+ * team: 1 single-reduction CG, 2 reference recurrence, 0 undivided mesh),"vec_reduce","xchg_comm" ; returns -1 for an unknown key */
 long nf_info(nf_handle h, const char *key);
 
 /* NeutFEM::SetBC (src/NeutFEM.cpp:337-345): attr per BoundaryID (include/NeutFEM.hpp:73-91).
@@ -218,7 +219,12 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   "nt_loads" (default 1): on undivided RT0-P0 meshes of more than "nt_min_cells" cells (default 8 000 000: from there on the streams no longer live in the
  *   256 MB memory-side cache between launches) the direction passes read their streams with non-temporal loads;
  *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
- *   "sep_fold" (default 1): slab teams form the separator values inside the accumulation pass of the z lines (no k_separators launch).
+ *   "sep_fold" (default 1): slab teams form the separator values inside the accumulation pass of the z lines (no k_separators launch);
+ *   "cg_single_reduce" (default 1): RT0-P0 slab teams run the CG with ONE cross-rank reduction per iteration (p.q, q.q, r.q and the measured
+ *   |r|^2 in one all-reduce of five doubles; r -= alpha q rides in the endpoint pass of the z lines; nf_info "cg_reductions" = 1) instead of
+ *   the reference recurrence's two ("vec_reduce" then picks between all-reducing the block partials themselves and k_finalize + scalars);
+ *   "xchg_comm" (default 0): the interface planes travel on a communicator of their own (created collectively before the next solve;
+ *   nf_info "xchg_comm") instead of sharing the one the all-reduces use.
  * nf_info keys beyond the mesh sizes: "last_path" (0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel, 3 one-XCD kernel),
  * "last_direct" (0 CG as configured, 1 dense S^-1, 2 CG to 1e-14 standing in). */
 int nf_set_option(nf_handle h, const char *key, long value);

@@ -87,3 +87,50 @@ def degenerate_inputs(nx, ny, nz, ng=2, seed=3):
     attrs = {1: (1, 2), 2: (1, 2, 3, 4), 3: (1, 2, 3, 4, 5, 6)}[dim]
     return dict(x_breaks=xb, y_breaks=yb, z_breaks=zb, D=D, SigR=SigR, NSF=NSF, Chi=Chi, SigS=SigS, bc_attr=np.array(attrs),
                 bc_type=np.zeros(len(attrs), dtype=int), ng=ng, coarse_factors=np.array([1, 1, 1]), kref=1.0)
+
+
+# ---- converged oracle runs, cached -----------------------------------------------------------------------------------------------------
+# The tight-tolerance parity tests compare the GPU with a CONVERGED oracle solve of the same input; on one host core those solves are most
+# of the GPU suite's wall time (the 40 x 33 x 3 shape: 30 s of oracle for 10 s of GPU paths).  The oracle is deterministic, so its outputs
+# for the heavy cases are committed under tests/golden/oracle_cache/ -- keyed by a hash of the inputs, the settings AND oracle/nf_oracle.c:
+# edit the oracle (or an input generator) and the key no longer matches, the test computes live again.  tests/golden/make_oracle_cache.py
+# regenerates the files; tests/test_oracle.py::test_oracle_cache_is_current recomputes entries and compares them bit for bit.
+ORACLE_CACHE = os.path.join(GOLDEN, "oracle_cache")
+
+
+def _oracle_key(inp, rt, p, tol, coarse):
+    import hashlib
+    h = hashlib.sha256()
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "nf_oracle.c"), "rb") as f:
+        h.update(f.read())
+    for k in ("x_breaks", "y_breaks", "z_breaks", "D", "SigR", "NSF", "Chi", "SigS", "bc_attr", "bc_type"):
+        a = np.ascontiguousarray(inp[k]); h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    h.update(repr((int(inp["ng"]), int(rt), int(p), tuple(float(t) for t in tol), None if coarse is None else tuple(int(c) for c in coarse))).encode())
+    return h.hexdigest()[:24]
+
+
+class SolvedOracle:
+    """what a parity test reads from a converged oracle run"""
+
+    def __init__(self, k, n_outer, phi, J, hist_k, hist_cg, cached):
+        self.k, self.n_outer, self.phi, self.J, self.hist_k, self.hist_cg, self.cached = float(k), int(n_outer), phi, J, hist_k, hist_cg, cached
+
+    def phi_dofs(self): return self.phi
+    def J_dofs(self): return self.J
+
+
+def solved_oracle(inp, rt=0, p=0, tol=TEST_TOL, coarse=None, want_J=True, write=False):
+    key = _oracle_key(inp, rt, p, tol, coarse)
+    path = os.path.join(ORACLE_CACHE, key + ".npz")
+    if os.path.exists(path) and not write:
+        z = np.load(path)
+        return SolvedOracle(z["k"], z["n_outer"], z["phi"], z["J"] if "J" in z.files else None, z["hist_k"], z["hist_cg"], True)
+    o = make_oracle(inp, rt, p); o.set_tol(*tol)
+    k = o.SolveKeff(True, [int(c) for c in coarse]) if coarse is not None else o.SolveKeff()
+    h = o.history()
+    r = SolvedOracle(k, h["n_outer"], o.phi_dofs().copy(), o.J_dofs().copy() if want_J else None, h["k"], h["cg"], False)
+    if write:
+        os.makedirs(ORACLE_CACHE, exist_ok=True)
+        extra = dict(J=r.J) if want_J else {}
+        np.savez_compressed(path, k=np.float64(r.k), n_outer=np.int64(r.n_outer), phi=r.phi, hist_k=r.hist_k, hist_cg=r.hist_cg, **extra)
+    return r

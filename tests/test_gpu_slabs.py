@@ -6,7 +6,7 @@ host-staged stand-in transport; RCCL between GPUs is exercised by the driver's m
 import numpy as np
 import pytest
 
-from helpers import make_hip, make_oracle, rel_l2, synthetic_inputs
+from helpers import make_hip, make_oracle, rel_l2, solved_oracle, synthetic_inputs
 from neutfem_amd.capi import HipTeam
 
 pytestmark = pytest.mark.gpu
@@ -65,13 +65,16 @@ def test_slabs_of_three_planes_are_refused():
     t.close()
 
 
+TEAM_TOL = (1e-10, 1e-10, 1e-10, 1000, 2000)
+
+
 @pytest.mark.parametrize("planes", [[(0, 48), (48, 96)], [(0, 32), (32, 64), (64, 96)]])
 def test_team_solve_keff_matches_undivided_and_oracle(planes):
     inp = synthetic_inputs(8, 6, 96, 2, seed=9)
-    tol = (1e-10, 1e-10, 1e-10, 1000, 2000)
-    o, s, t = make_oracle(inp), make_hip(inp), make_team(inp, planes)
-    o.set_tol(*tol); s.set_tol(*tol); t.set_tol(*tol)
-    ko = o.SolveKeff(); ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
+    tol = TEAM_TOL
+    o, s, t = solved_oracle(inp, 0, 0, tol, want_J=False), make_hip(inp), make_team(inp, planes)
+    s.set_tol(*tol); t.set_tol(*tol)
+    ko = o.k; ks, ns = s.solve_keff(); kt, nt = t.solve_keff()
     phi_t = t.get_phi_local().ravel()
     assert abs(kt - ks) / ks < 1e-10 and abs(kt - ko) / ko < 1e-9
     assert rel_l2(phi_t, s.get_phi().ravel()) < 1e-8

@@ -344,3 +344,30 @@ def test_reference_quirks():
     q = OracleNeutFEM(0, 0, 1, np.array([0.0, 2.0, 4.0]), np.array([0.0, 3.0, 6.0]), np.array([0.0]))
     A, _, _ = q.local_matrices(0, 1.0, 0.0)
     assert A[0, 0] == pytest.approx((3.0 / 2.0) * 2 * 2 / 3) and A[2, 2] == pytest.approx((2.0 / 3.0) * 2 * 2 / 3)
+
+
+def test_oracle_cache_is_current():
+    """tests/golden/oracle_cache/ holds converged oracle runs of the heavy tight-tolerance GPU parity cases (helpers.solved_oracle: on one
+    core those solves were most of the GPU suite's wall time).  Every file is keyed by a hash of its inputs, its settings and
+    oracle/nf_oracle.c: (i) every case of the generator has its file under today's key -- after an edit of the oracle or of an input
+    generator this fails and says so (the GPU tests would still be right: a missing key makes them compute live); (ii) entries
+    recomputed here equal the committed ones bit for bit."""
+    import importlib.util, os, sys
+    from helpers import ORACLE_CACHE, _oracle_key, solved_oracle
+    spec = importlib.util.spec_from_file_location("make_oracle_cache", os.path.join(os.path.dirname(__file__), "golden", "make_oracle_cache.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    cases = gen.cases()
+    assert len(cases) == 19
+    live = 0
+    for label, inp_spec, kw in cases:
+        inp = gen.build_input(inp_spec)
+        key = _oracle_key(inp, kw["rt"], kw["p"], kw["tol"], kw.get("coarse"))
+        assert os.path.exists(os.path.join(ORACLE_CACHE, key + ".npz")), f"{label}: no committed oracle run under today's key -- run tests/golden/make_oracle_cache.py"
+        if inp["D"].size <= 2 * 400 and live < 5:                 # the small ones again, live
+            a = solved_oracle(inp, **kw)
+            from helpers import make_oracle
+            o = make_oracle(inp, kw["rt"], kw["p"]); o.set_tol(*kw["tol"]); k = o.SolveKeff()
+            assert a.cached and k == a.k and o.info("last_outer") == a.n_outer and np.array_equal(o.phi_dofs(), a.phi) and np.array_equal(o.J_dofs(), a.J), label
+            assert np.array_equal(o.history()["cg"], a.hist_cg), label
+            live += 1
+    assert live >= 4
