@@ -131,6 +131,12 @@ int nf_solve_keff(nf_handle h, const nf_keff_opts *opts, double *keff, int *n_ou
  * makes every rank return (the failing one with its own code, the others with NF_ERR_REMOTE); a collective that does not complete
  * within NEUTFEM_COMM_TIMEOUT_S seconds (default 120) returns NF_ERR_COMM. */
 int nf_progress(nf_handle h, long *outers_done);
+/* The progress line of the outer loop (src/NeutFEM.cpp:1791-1796: "It n : k = ... dk = ... dphi = ..." every 5th iteration) WHILE the solve
+ * runs: fn(user, it, keff, dk, dphi) is called on the calling thread after every outer iteration of the host-driven loop -- the path every
+ * mesh beyond ~28 k unknowns per group takes, where a solve lasts seconds to minutes.  The in-kernel paths (resident, one-XCD, diagonal device
+ * loop: milliseconds) have no host between their outers; their lines come from nf_get_history afterwards.  fn = NULL removes it. */
+typedef void (*nf_progress_fn)(void *user, int outer, double keff, double dk, double dphi);
+int nf_set_progress_callback(nf_handle h, nf_progress_fn fn, void *user);
 
 /* CMFD acceleration (src/NeutFEM.cpp:662-1017, include/NeutFEM.hpp:119-143,232-235): NeutFEM::InitializeCMFD
  * (D-tilde for every direction, D-hat = 0; idempotent until the next nf_build), SetCMFDRelaxation, and a probe that

@@ -15,7 +15,7 @@ SYMBOLS = [
     "nf_comm_init", "nf_comm_info", "nf_comm_selftest", "nf_team_schur_apply", "nf_info", "nf_set_bc", "nf_upload_xs", "nf_build",
     "nf_schur_apply", "nf_solve_group", "nf_build_diagonal_cache", "nf_get_diagonal_cache", "nf_solve_keff",
     "nf_solve_coarse", "nf_coarsen", "nf_prolong", "nf_timers", "nf_initialize_cmfd", "nf_set_cmfd_relaxation", "nf_get_cmfd_coefficients", "nf_solve_adjoint", "nf_get_phi_adj", "nf_set_phi", "nf_get_phi", "nf_get_J", "nf_reset_flux", "nf_set_warm_state",
-    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy", "nf_progress", "nf_local_matrices",
+    "nf_get_warm_state", "nf_get_history", "nf_profile_get", "nf_profile_reset", "nf_time_schur_apply", "nf_time_device_copy", "nf_progress", "nf_set_progress_callback", "nf_local_matrices",
     "nf_set_option", "nf_mem_info", "nf_dev_alloc", "nf_dev_free", "nf_memcpy_h2d", "nf_memcpy_d2h", "nf_synchronize", "nf_stream",
 ]
 
@@ -81,6 +81,7 @@ def load():
     L.nf_time_schur_apply.argtypes = [vp, C.c_int, C.c_int, dp]
     L.nf_time_device_copy.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.nf_progress.argtypes = [vp, C.POINTER(C.c_long)]
+    L.nf_set_progress_callback.argtypes = [vp, vp, vp]
     L.nf_local_matrices.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp, dp, C.c_int, C.c_int, dp]
     L.nf_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.nf_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]

@@ -128,6 +128,15 @@ public:
         o.use_diagonal_solver = use_diag; o.solver_type = (int)solver_; o.solver_type_pushed = solver_pushed_; o.profile = 0;
         return o;
     }
+    int printed_upto_ = 0;                                        // first outer whose progress line has not been printed yet (multiple of 5)
+    static void progress_line(void *self, int it, double keff, double dk, double dphi)
+    {
+        NeutFEM *me = static_cast<NeutFEM *>(self);
+        if (it % 5 != 0) return;
+        std::cout << "  It " << std::setw(4) << it << " : k = " << std::fixed << std::setprecision(8) << keff << "  dk = " << std::scientific
+                  << std::setprecision(2) << dk << "  dphi = " << dphi << std::defaultfloat << std::endl;
+        me->printed_upto_ = it + 5;
+    }
     double SolveKeff(bool use_coarse_init, const std::vector<int> &coarse_factors, bool use_diagonal_solver, bool use_cmfd)
     {
         need_built("SolveKeff");
@@ -141,12 +150,18 @@ public:
         o.use_cmfd = use_cmfd ? 1 : 0;
         chk(nf_set_cmfd_relaxation(h_, cmfd_omega_));
         double k = 1.0; int nout = 0;
-        chk(nf_solve_keff(h_, &o, &k, &nout));
+        // the reference prints its progress line every 5th outer DURING the solve (src/NeutFEM.cpp:1791-1796): the host-driven loop calls back after
+        // every outer; the in-kernel paths (milliseconds) have no host in between, their lines follow from the recorded history
+        printed_upto_ = 0;
+        chk(nf_set_progress_callback(h_, verb_ >= VerbosityLevel::NORMAL ? &NeutFEM::progress_line : nullptr, this));
+        const int rc_solve = nf_solve_keff(h_, &o, &k, &nout);
+        (void)nf_set_progress_callback(h_, nullptr, nullptr);
+        chk(rc_solve);
         chk(nf_get_phi(h_, Phi_.data()));
         if (verb_ >= VerbosityLevel::NORMAL) {
             std::vector<double> hk(nout), hdk(nout), hdp(nout);
             nf_get_history(h_, hk.data(), hdk.data(), hdp.data(), nullptr, nout);
-            for (int it = 0; it < nout; it += 5)
+            for (int it = printed_upto_; it < nout; it += 5)
                 std::cout << "  It " << std::setw(4) << it << " : k = " << std::fixed << std::setprecision(8) << hk[it] << "  dk = " << std::scientific
                           << std::setprecision(2) << hdk[it] << "  dphi = " << hdp[it] << std::defaultfloat << std::endl;
             if (nout < max_outer_) std::cout << "  Convergence en " << nout << " iterations" << std::endl;

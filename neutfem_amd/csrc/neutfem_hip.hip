@@ -145,6 +145,7 @@ struct nf_team {
     int inject_rank = -1; long inject_iter = -1;
     int inject_outer = -1; char inject_where = 0;   // NEUTFEM_INJECT_FAIL=<rank>:o<n> / :e<n> (start / end of outer n, outside the CG loop), :a (next exchange-only collective)
     double comm_timeout_s = 120.0;  // multi-rank teams: a stream that does not drain for this long means a peer is gone (NEUTFEM_COMM_TIMEOUT_S)
+    nf_progress_fn progress_fn = nullptr; void *progress_user = nullptr;   // nf_set_progress_callback
     volatile long outers_done = 0;  // completed outer iterations of the running / last SolveKeff (bench.py's watchdog polls it from another thread)
     bool linked_ready = false;      // separator diagonals exchanged
     int sep_sweeps = 0;             // Jacobi sweeps on the separator system (0: slabs thick enough for it to be diagonal to rounding)
@@ -2973,6 +2974,7 @@ static int solve_keff_impl(nf_team *T, const nf_keff_opts *o, double *keff_out, 
         T->hist_k.push_back(keff); T->hist_dk.push_back(dk); T->hist_dphi.push_back(dphi);
         T->last_outer = it + 1;
         __atomic_store_n(&T->outers_done, (long)(it + 1), __ATOMIC_RELEASE);
+        if (T->progress_fn) T->progress_fn(T->progress_user, it, keff, dk, dphi);
         if (dk < o->tol_keff && dphi < o->tol_flux && !T->poisoned) break;        // :1799-1802 (a poisoned rank stays in the schedule until the flag has gone round)
     }
 #undef NF_OUTER_CHK
@@ -3000,6 +3002,13 @@ int nf_solve_keff(nf_handle S, const nf_keff_opts *o, double *keff, int *n_outer
     HIPCHK(hipSetDevice(S->device));
     __atomic_store_n(&S->team->outers_done, 0L, __ATOMIC_RELEASE);
     return solve_keff_impl(S->team, o, keff, n_outer);
+}
+
+int nf_set_progress_callback(nf_handle S, nf_progress_fn fn, void *user)
+{
+    if (!S) return fail(NF_ERR_ARG, "null handle");
+    S->team->progress_fn = fn; S->team->progress_user = user;
+    return NF_OK;
 }
 
 // Outer iterations the running (or last) nf_solve_keff has completed on the host-driven path.  Safe to call from another thread

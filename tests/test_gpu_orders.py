@@ -41,13 +41,18 @@ def test_solve_keff_golden_higher_order(name, rt, p):
     s.close()
 
 
-@pytest.mark.parametrize("rt,p,shape", [(1, 1, (8, 7, 6)), (2, 2, (5, 4, 4)), (2, 1, (20, 14, 1)), (1, 1, (40, 1, 1))])
+ORDER_CASES = [(1, 1, (8, 7, 6)), (2, 2, (5, 4, 4)), (2, 1, (20, 14, 1)), (1, 1, (40, 1, 1))]
+ORDER_TOL = (1e-11, 1e-11, 1e-11, 1500, 3000)
+
+
+@pytest.mark.parametrize("rt,p,shape", ORDER_CASES)
 def test_solve_keff_orders_vs_oracle(rt, p, shape):
+    from helpers import solved_oracle
     inp = synthetic_inputs(*shape, ng=2, seed=5 + rt + p)
-    tol = (1e-11, 1e-11, 1e-11, 1500, 3000)
-    o, s = make_oracle(inp, rt, p), make_hip(inp, rt, p)
-    o.set_tol(*tol); s.set_tol(*tol)
-    ko = o.SolveKeff(); ks, n = s.solve_keff()
+    tol = ORDER_TOL
+    o, s = solved_oracle(inp, rt, p, tol, want_J=False), make_hip(inp, rt, p)       # the oracle's converged run: committed (helpers.solved_oracle)
+    s.set_tol(*tol)
+    ko = o.k; ks, n = s.solve_keff()
     assert abs(ks - ko) / ko < 1e-9
     assert rel_l2(s.get_phi().ravel(), o.phi_dofs().ravel()) < 1e-8
     s.close()
