@@ -121,7 +121,10 @@ struct nf_team {
     // first contact with RCCL on several GPUs can A/B "one communicator driven from two streams" against "one communicator per stream"
     ncclComm_t comm_x = nullptr; int opt_xchg_comm = 0;
     // single-reduction CG on slab teams (Cg1 in nf_kernels.h): one all-reduce per CG iteration instead of two
-    int opt_cg1 = 1, last_cg_reductions = 0;
+    // -1 (default): where it pays -- slabs of at most cg1_max_cells cells on every rank.  The form moves r -= alpha q and three more sums into the two z
+    // passes: +4 us per rank and iteration at 2 M cells per slab (256^3 on 8 GPUs) against one all-reduce saved, but +40 us at 16.8 M cells
+    // (512^3 on 8 GPUs), more than an all-reduce costs (profiles/r04_d_*, r04_j_*).  The largest slab of the TEAM decides (all-reduced in team_prepare).
+    int opt_cg1 = -1, last_cg_reductions = 0; long cg1_max_cells = 6L << 20, team_max_cells = 0;
     bool rccl_reduce = false;       // scalar reductions go through ncclAllReduce (nproc > 1, or forced for testing)
     double *d_partials = nullptr; long partial_stride = 0, slab_cap = 0;
     CgScalars *d_cg = nullptr;
@@ -1012,6 +1015,7 @@ static int team_prepare(nf_team *T)
     // multi-rank team takes part in this all-reduce, eligible or not (an ineligible rank contributes zeros, which makes max != -min
     // and switches the path off everywhere): a collective behind a rank-local condition would be a hang.
     T->vec_ok = false;
+    T->team_max_cells = 0; for (auto *X : T->slabs) T->team_max_cells = std::max(T->team_max_cells, X->N);
     if (T->rccl_reduce && T->nproc > 1) {
         nf_solver *S = T->slabs[0];
         const bool eligible = T->slabs.size() == 1 && S->nloc == 1 && S->dim == 3 && (S->if_lo || S->if_hi);
@@ -1023,11 +1027,12 @@ static int team_prepare(nf_team *T)
             if (rc != NF_OK) np = 0;                              // not an error here: the scalar route serves
         }
         const int nr = eligible ? grid_for(S->nphi) : 0;
-        double v[4] = { (double)np, -(double)np, (double)nr, -(double)nr };
+        double v[5] = { (double)np, -(double)np, (double)nr, -(double)nr, (double)T->team_max_cells };
         HIPCHK(hipMemcpyAsync(T->d_red, v, sizeof v, hipMemcpyHostToDevice, T->stream));
-        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 4, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
+        NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 5, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
         HIPCHK(hipMemcpyAsync(v, T->d_red, sizeof v, hipMemcpyDeviceToHost, T->stream));
         HIPCHK(hipStreamSynchronize(T->stream));
+        T->team_max_cells = (long)v[4];                              // every rank takes the same decision about the CG form (cg_solve)
         T->vec_cnt_pq = np; T->vec_cnt_rr = nr;
         T->vec_stride = T->slab_cap + 2;
         T->vec_ok = eligible && v[0] == -v[1] && v[2] == -v[3] && np > 0 && np < T->slab_cap && nr > 0 && nr < T->slab_cap;
@@ -1649,7 +1654,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     // totals (d_red[2] = |r|^2, d_red[0] = p.q, each followed by the ranks' error flags) and derive beta / alpha and the stop tests themselves: no k_cg_logic launches
     const bool tlean = fused && T->opt_lean && !team_is_single(T);
     // single-reduction variant of it (Cg1): one reduction per iteration; needs the 8-cell-segment z passes on every local slab
-    bool sr = tlean && T->opt_cg1 != 0;
+    bool sr = tlean && (T->opt_cg1 > 0 || (T->opt_cg1 < 0 && T->team_max_cells <= T->cg1_max_cells));
     for (auto *S : T->slabs) sr = sr && S->dim == 3 && S->nb == 0 && (T->opt_s_seg == 0 || T->opt_s_seg == 8) && S->nz <= 1024;
     T->last_cg_reductions = team_is_single(T) ? 0 : (sr ? 1 : 2);
     // fused-direction variant on top of the lean one (small / medium meshes): two launches per iteration, see k_apply3
@@ -2213,7 +2218,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     if (CT) {
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
-        CT->opt_cg1 = T->opt_cg1; CT->comm_x = T->comm_x; CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
+        CT->opt_cg1 = T->opt_cg1; CT->cg1_max_cells = T->cg1_max_cells; CT->comm_x = T->comm_x; CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
         CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_cgx = T->opt_cgx; CT->opt_keffx = T->opt_keffx; CT->xcd_min_cells = T->xcd_min_cells; CT->xcd_max_cells = T->xcd_max_cells; CT->xcd_id = T->xcd_id; CT->xcd_groups = T->xcd_groups; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
@@ -3349,7 +3354,8 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
     else if (!strcmp(key, "vec_reduce")) T->opt_vec_reduce = value != 0;
-    else if (!strcmp(key, "cg_single_reduce")) T->opt_cg1 = value != 0;
+    else if (!strcmp(key, "cg_single_reduce")) T->opt_cg1 = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(key, "cg_single_reduce_max_cells")) T->cg1_max_cells = std::max(0L, value);
     else if (!strcmp(key, "xchg_comm")) { T->opt_xchg_comm = value != 0; if (T->nproc > 1) T->linked_ready = false; }
     else if (!strcmp(key, "xy_overlap")) T->opt_xy_overlap = value != 0;
     else if (!strcmp(key, "xy_overlap_max_cells")) T->xy_overlap_max_cells = std::max(0L, value);
