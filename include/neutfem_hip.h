@@ -226,10 +226,13 @@ int nf_time_device_copy(nf_handle h, size_t bytes, int reps, double *gbps);
  *   256 MB memory-side cache between launches) the direction passes read their streams with non-temporal loads;
  *   "outer_dev" (default 1) keeps the outer loop of the diagonal-Schur path on the device (undivided mesh, no CMFD);
  *   "sep_fold" (default 1): slab teams form the separator values inside the accumulation pass of the z lines (no k_separators launch);
- *   "cg_single_reduce" (default -1 = where it pays: largest slab of the team at most "cg_single_reduce_max_cells" cells, default 6 Mi; 1 always,
+ *   "cg_single_reduce" (default -1 = while the largest slab of the team has at most "cg_single_reduce_max_cells" cells, default unlimited; 1 always,
  *   0 never): RT0-P0 slab teams run the CG with ONE cross-rank reduction per iteration (p.q, q.q, r.q and the measured |r|^2 in one all-reduce
  *   of five doubles; r -= alpha q rides in the endpoint pass of the z lines; nf_info "cg_reductions" = 1) instead of the reference
  *   recurrence's two ("vec_reduce" then picks between all-reducing the block partials themselves and k_finalize + scalars);
+ *   "endpoint_weights" (default 1): that CG's endpoint pass forms the chain-end responses of every z line as weighted sums of the line's cells
+ *   (weights measured once per BuildMatrices with the chain solve itself: nz launches per group, 16 B per cell and group of HBM) instead of
+ *   solving the chain -- a streaming kernel with the deferred CG update in the same sweep (nf_info "endpoint_weights");
  *   "xchg_comm" (default 0): the interface planes travel on a communicator of their own (created collectively before the next solve;
  *   nf_info "xchg_comm") instead of sharing the one the all-reduces use.
  * nf_info keys beyond the mesh sizes: "last_path" (0 host-driven outer loop, 1 diagonal device loop, 2 resident kernel, 3 one-XCD kernel),

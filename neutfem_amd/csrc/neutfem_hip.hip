@@ -121,10 +121,12 @@ struct nf_team {
     // first contact with RCCL on several GPUs can A/B "one communicator driven from two streams" against "one communicator per stream"
     ncclComm_t comm_x = nullptr; int opt_xchg_comm = 0;
     // single-reduction CG on slab teams (Cg1 in nf_kernels.h): one all-reduce per CG iteration instead of two
-    // -1 (default): where it pays -- slabs of at most cg1_max_cells cells on every rank.  The form moves r -= alpha q and three more sums into the two z
-    // passes: +4 us per rank and iteration at 2 M cells per slab (256^3 on 8 GPUs) against one all-reduce saved, but +40 us at 16.8 M cells
-    // (512^3 on 8 GPUs), more than an all-reduce costs (profiles/r04_d_*, r04_j_*).  The largest slab of the TEAM decides (all-reduced in team_prepare).
-    int opt_cg1 = -1, last_cg_reductions = 0; long cg1_max_cells = 6L << 20, team_max_cells = 0;
+    // -1 (default): slabs of at most cg1_max_cells cells on every rank (the largest slab of the TEAM decides, all-reduced in team_prepare).  With the
+    // chain-solve endpoint pass the form cost 4 us per rank and iteration at 2 M cells per slab and 40 us at 16.8 M -- more than an all-reduce -- and
+    // was limited to small slabs; with the weighted-sum endpoint pass (k_endpoint_w) it is FASTER than the two-reduction route in device time alone
+    // at every size measured (256^3 as 2 / 4 / 8 slabs: -6.5 / -7.9 / -5.5 %, 512^3 as 8: -3.2 %; profiles/r04_d_*), so the limit is out of the way.
+    int opt_cg1 = -1, last_cg_reductions = 0; long cg1_max_cells = 1L << 40, team_max_cells = 0;
+    int opt_endpoint_w = 1, last_endpoint_w = 0;   // its endpoint pass as two weighted sums per line (k_endpoint_w) instead of a chain solve
     bool rccl_reduce = false;       // scalar reductions go through ncclAllReduce (nproc > 1, or forced for testing)
     double *d_partials = nullptr; long partial_stride = 0, slab_cap = 0;
     CgScalars *d_cg = nullptr;
@@ -225,6 +227,7 @@ struct nf_solver {
     double *d_sinv_lo = nullptr, *d_sinv_hi = nullptr;  // ng * nlines[2]
     double *d_clo = nullptr, *d_chi = nullptr, *d_rlo = nullptr, *d_rhi = nullptr, *d_ulo = nullptr, *d_uhi = nullptr;
     double *d_ctlo = nullptr, *d_cthi = nullptr, *d_elo = nullptr, *d_ehi = nullptr, *d_relo = nullptr, *d_rehi = nullptr;   // separator sweeps (thin slabs)
+    double *d_Wlo = nullptr, *d_Whi = nullptr; bool w_valid = false; int sr_cnt3 = 0;   // endpoint functionals of the z lines (k_endpoint_w), ng * N each; |r|^2 partials of its last launch
     // state
     double *d_phi = nullptr, *d_raw = nullptr;          // current iterate / raw group solutions, ng*N
     double *d_p0 = nullptr, *d_p1 = nullptr;            // Chebyshev history
@@ -546,6 +549,7 @@ int nf_destroy(nf_handle S)
     for (int d = 0; d < 3; ++d) { dfree(S->d_L[d]); dfree(S->d_DR[d]); dfree(S->d_D0[d]); }
     dfree(S->d_alo); dfree(S->d_ahi); dfree(S->d_hlo); dfree(S->d_hhi); dfree(S->d_gfl); dfree(S->d_sinv_lo); dfree(S->d_sinv_hi);
     dfree(S->d_clo); dfree(S->d_chi); dfree(S->d_rlo); dfree(S->d_rhi); dfree(S->d_ulo); dfree(S->d_uhi);
+    dfree(S->d_Wlo); dfree(S->d_Whi);
     dfree(S->d_Jz); dfree(S->d_Jzb); dfree(S->d_ctlo); dfree(S->d_cthi); dfree(S->d_elo); dfree(S->d_ehi); dfree(S->d_relo); dfree(S->d_rehi);
     dfree(S->d_phi); dfree(S->d_raw); dfree(S->d_p0); dfree(S->d_p1);
     dfree(S->d_tf); dfree(S->d_rhs); dfree(S->d_r); dfree(S->d_p); dfree(S->d_q); dfree(S->d_p2); dfree(S->d_qy); dfree(S->d_qz);
@@ -674,7 +678,7 @@ long nf_info(nf_handle S, const char *key)
     K("dim", S->dim); K("nx", S->nx); K("ny", S->ny); K("nz", S->nz); K("ne", S->N); K("ng", S->ng);
     K("n_phi", S->nphi); K("n_J", S->nJ); K("n_loc", S->nloc); K("rt_order", S->k); K("p_order", S->m); K("last_outer", T->last_outer);
     K("last_cg_total", T->last_cg_total); K("coarse_outer", T->coarse_outer); K("device", S->device);
-    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce); K("cg_reductions", T->last_cg_reductions); K("xchg_comm", T->comm_x ? 1 : 0); K("last_xcd", T->last_xcd); K("xcd_solves", T->xcd_solves); K("xcd_refused", T->xcd_refused);
+    K("last_path", T->last_path); K("last_resident_serial", T->last_resident_serial); K("last_direct", T->last_direct); K("direct_standin_unconverged", T->standin_unconverged); K("n_local_slabs", T->slabs.size()); K("n_ranks", T->nproc); K("rank", T->rank); K("vec_reduce", T->last_vec_reduce); K("cg_reductions", T->last_cg_reductions); K("endpoint_weights", T->last_endpoint_w); K("xchg_comm", T->comm_x ? 1 : 0); K("last_xcd", T->last_xcd); K("xcd_solves", T->xcd_solves); K("xcd_refused", T->xcd_refused);
 #undef K
     return -1;
 }
@@ -1038,6 +1042,31 @@ static int team_prepare(nf_team *T)
         T->vec_ok = eligible && v[0] == -v[1] && v[2] == -v[3] && np > 0 && np < T->slab_cap && nr > 0 && nr < T->slab_cap;
         if (T->vec_ok && !T->d_vec) { NFCHK(dalloc(&T->d_vec, (size_t)T->vec_stride * 2)); HIPCHK(hipMemset(T->d_vec, 0, (size_t)T->vec_stride * 2 * sizeof(double))); }
     }
+    // endpoint functionals for the single-reduction CG (k_endpoint_w): the response of c_lo / c_hi to the unit vector of every plane, measured with
+    // the endpoint pass itself -- nz launches per group, once per BuildMatrices
+    for (auto *S : T->slabs) S->w_valid = false;
+    if (T->opt_endpoint_w && T->opt_cg1 != 0 && (T->opt_cg1 > 0 || T->team_max_cells <= T->cg1_max_cells))
+        for (auto *S : T->slabs) {
+            if (!(S->if_lo || S->if_hi) || S->nb != 0 || S->dim != 3 || S->nloc != 1) continue;
+            const size_t NG = (size_t)S->N * S->ng; const long nxy = S->nlines[2];
+            if (!S->d_Wlo) { NFCHK(dalloc(&S->d_Wlo, NG)); NFCHK(dalloc(&S->d_Whi, NG)); }
+            HIPCHK(hipMemsetAsync(S->d_Wlo, 0, NG * sizeof(double), T->stream)); HIPCHK(hipMemsetAsync(S->d_Whi, 0, NG * sizeof(double), T->stream));
+            HIPCHK(hipMemsetAsync(S->d_p, 0, (size_t)S->N * sizeof(double), T->stream));
+            const Geom G = make_geom(S);
+            const unsigned gf = (unsigned)grid_for(nxy);
+            for (int g = 0; g < S->ng; ++g)
+                for (int k = 0; k < S->nz; ++k) {
+                    double *plane = S->d_p + (size_t)k * nxy;
+                    hipLaunchKernelGGL(k_fill_const, dim3(gf), dim3(256), 0, T->stream, plane, nxy, 1.0);
+                    NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, S->d_p, S->d_q), G, 0, nullptr, nullptr, nullptr, 1));
+                    if (S->if_lo) HIPCHK(hipMemcpyAsync(S->d_Wlo + (size_t)g * S->N + (size_t)k * nxy, S->d_clo, (size_t)nxy * sizeof(double), hipMemcpyDeviceToDevice, T->stream));
+                    if (S->if_hi) HIPCHK(hipMemcpyAsync(S->d_Whi + (size_t)g * S->N + (size_t)k * nxy, S->d_chi, (size_t)nxy * sizeof(double), hipMemcpyDeviceToDevice, T->stream));
+                    hipLaunchKernelGGL(k_fill_const, dim3(gf), dim3(256), 0, T->stream, plane, nxy, 0.0);
+                }
+            HIPCHK(hipStreamSynchronize(T->stream));
+            HIPCHK(hipGetLastError());
+            S->w_valid = true;
+        }
     T->linked_ready = true;
     return NF_OK;
 }
@@ -1119,7 +1148,10 @@ static int team_reduce(nf_team *T, const std::vector<int> &counts, double *red)
 static int team_reduce_sr(nf_team *T, const std::vector<int> &counts)
 {
     PartSegs ps = segs_for(T, counts);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(256), 0, T->stream, (const double *)T->d_partials, ps, T->partial_stride, T->d_red, (const double *)T->d_errsrc);
+    std::vector<int> c3(counts);                                 // row 3: the endpoint pass's own block count where k_endpoint_w ran (0 on a poisoned rank)
+    for (size_t i = 0; i < c3.size(); ++i) if (T->slabs[i]->sr_cnt3 > 0 && counts[i] > 0) c3[i] = T->slabs[i]->sr_cnt3;
+    PartSegs ps3 = segs_for(T, c3);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(256), 0, T->stream, (const double *)T->d_partials, ps, ps3, T->partial_stride, T->d_red, (const double *)T->d_errsrc);
     if (T->rccl_reduce) { TRACE_COMM("rank %d allreduce single-reduction count=5 poisoned=%d", T->rank, (int)T->poisoned); NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 5, NCCL_DOUBLE, NCCL_SUM, T->comm, T->stream)); }
     return NF_OK;
 }
@@ -1340,6 +1372,18 @@ static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double
     for (int i = 0; i < ns; ++i) {
         nf_solver *S = T->slabs[i];
         if (!(S->if_lo || S->if_hi)) continue;
+        S->sr_cnt3 = 0;
+        if (S->cg1.red && S->w_valid && T->opt_endpoint_w && S->fuse.p == xs[i]) {
+            // single-reduction CG: the chain-end responses as weighted sums of the line's cells + the deferred CG update (k_endpoint_w)
+            const dim3 gr((unsigned)((S->nx + 63) / 64), (unsigned)S->ny);
+            if ((long)gr.x * gr.y <= T->slab_cap) {
+                hipLaunchKernelGGL(k_endpoint_w, gr, dim3(256), 0, T->stream, S->fuse.p, const_cast<double *>(S->fuse.r), (const double *)S->d_q, S->fuse.xsol,
+                                   (const double *)(S->d_Wlo + (size_t)g * S->N), (const double *)(S->d_Whi + (size_t)g * S->N), S->d_clo, S->d_chi,
+                                   S->nx, S->ny, S->nz, S->if_lo, S->if_hi, S->cg1, cg, T->d_partials + 3 * T->partial_stride + (long)S->slab_index * T->slab_cap);
+                S->sr_cnt3 = (int)(gr.x * gr.y); T->last_endpoint_w = 1;
+                continue;
+            }
+        }
         NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, cg, nullptr, 1));
     }
     if (after_z1) (void)hipEventRecord(after_z1, T->stream);
@@ -1656,7 +1700,7 @@ static int cg_solve(nf_team *T, int g, const std::vector<const double *> &rhs, c
     // single-reduction variant of it (Cg1): one reduction per iteration; needs the 8-cell-segment z passes on every local slab
     bool sr = tlean && (T->opt_cg1 > 0 || (T->opt_cg1 < 0 && T->team_max_cells <= T->cg1_max_cells));
     for (auto *S : T->slabs) sr = sr && S->dim == 3 && S->nb == 0 && (T->opt_s_seg == 0 || T->opt_s_seg == 8) && S->nz <= 1024;
-    T->last_cg_reductions = team_is_single(T) ? 0 : (sr ? 1 : 2);
+    T->last_cg_reductions = team_is_single(T) ? 0 : (sr ? 1 : 2); T->last_endpoint_w = 0;
     // fused-direction variant on top of the lean one (small / medium meshes): two launches per iteration, see k_apply3
     Fuse3Plan f3;
     nf_solver *S0 = T->slabs[0];
@@ -2218,7 +2262,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
     if (CT) {
         CT->comm = T->comm; CT->nproc = T->nproc; CT->rank = T->rank; CT->rccl_reduce = T->rccl_reduce; CT->linked_ready = false;
         // tuning options (nf_set_option) apply to the coarse solve as well
-        CT->opt_cg1 = T->opt_cg1; CT->cg1_max_cells = T->cg1_max_cells; CT->comm_x = T->comm_x; CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
+        CT->opt_cg1 = T->opt_cg1; CT->cg1_max_cells = T->cg1_max_cells; CT->opt_endpoint_w = T->opt_endpoint_w; CT->comm_x = T->comm_x; CT->opt_fuse = T->opt_fuse; CT->opt_lean = T->opt_lean; CT->opt_sepfold = T->opt_sepfold; CT->opt_lean_grid = T->opt_lean_grid; CT->lean_max_cells = T->lean_max_cells;
         CT->opt_fuse3 = T->opt_fuse3; CT->fuse3_max_cells = T->fuse3_max_cells; CT->opt_cgx = T->opt_cgx; CT->opt_keffx = T->opt_keffx; CT->xcd_min_cells = T->xcd_min_cells; CT->xcd_max_cells = T->xcd_max_cells; CT->xcd_id = T->xcd_id; CT->xcd_groups = T->xcd_groups; CT->opt_resident = T->opt_resident; CT->opt_resident_lds = T->opt_resident_lds; CT->opt_resident_serial = T->opt_resident_serial; CT->opt_resident_two_sided = T->opt_resident_two_sided; CT->resident_max_dofs = T->resident_max_dofs; CT->resident_serial_max_dofs = T->resident_serial_max_dofs;
         CT->cg_batch = T->cg_batch; CT->opt_outer_dev = T->opt_outer_dev; CT->direct_max_dofs = T->direct_max_dofs;
     }
@@ -3354,8 +3398,9 @@ int nf_set_option(nf_handle S, const char *key, long value)
     else if (!strcmp(key, "s_pair")) { /* retired: the two-columns-per-thread variant lost to occupancy */ }
     else if (!strcmp(key, "s_wsmin")) T->opt_wsmin = (int)std::max(0L, std::min(100000L, value));
     else if (!strcmp(key, "vec_reduce")) T->opt_vec_reduce = value != 0;
-    else if (!strcmp(key, "cg_single_reduce")) T->opt_cg1 = value < 0 ? -1 : (value != 0);
-    else if (!strcmp(key, "cg_single_reduce_max_cells")) T->cg1_max_cells = std::max(0L, value);
+    else if (!strcmp(key, "cg_single_reduce")) { T->opt_cg1 = value < 0 ? -1 : (value != 0); T->linked_ready = false; }
+    else if (!strcmp(key, "cg_single_reduce_max_cells")) { T->cg1_max_cells = std::max(0L, value); T->linked_ready = false; }
+    else if (!strcmp(key, "endpoint_weights")) { T->opt_endpoint_w = value != 0; T->linked_ready = false; }
     else if (!strcmp(key, "xchg_comm")) { T->opt_xchg_comm = value != 0; if (T->nproc > 1) T->linked_ready = false; }
     else if (!strcmp(key, "xy_overlap")) T->opt_xy_overlap = value != 0;
     else if (!strcmp(key, "xy_overlap_max_cells")) T->xy_overlap_max_cells = std::max(0L, value);

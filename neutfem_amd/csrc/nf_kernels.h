@@ -362,14 +362,14 @@ __device__ __forceinline__ bool cg1_step(const Cg1 &c, bool writer, double *alph
 // The four rows of block partials of one iteration -> red[0..3] (+ this rank's error flag -> red[4]): one wavefront per row, every lane
 // sums the entries l, l + 64, ... of each slab's segment with eight loads in flight, one cross-lane sum at the end.  No barrier, no
 // serial tail: ~3 us where k_finalize (one row and one segment at a time behind block-wide barriers) took 58 us for 4 x 8 x 256 partials.
-__global__ __launch_bounds__(256) void k_reduce_rows(const double *__restrict__ partials, PartSegs segs, long stride, double *__restrict__ red,
+__global__ __launch_bounds__(256) void k_reduce_rows(const double *__restrict__ partials, PartSegs segs, PartSegs segs3, long stride, double *__restrict__ red,
                                                      const double *__restrict__ errsrc)
 {
     const int row = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double *p = partials + (long)row * stride;
     double s = 0.0;
     for (int sg = 0; sg < segs.n; ++sg) {
-        const double *q = p + segs.off[sg]; const int cnt = segs.cnt[sg];
+        const double *q = p + segs.off[sg]; const int cnt = row == 3 ? segs3.cnt[sg] : segs.cnt[sg];   // row 3 (|r|^2) comes from the endpoint pass, whose grid may differ
         int i = lane;
         for (; i + 7 * 64 < cnt; i += 8 * 64) {
             double v[8];
@@ -1406,6 +1406,57 @@ __global__ __launch_bounds__(SLAB ? 512 : 1024, SLAB ? (NB > 0 ? 2 : (SF ? (SR ?
             if (threadIdx.x == 0) { partials[pidx + sa.sr_stride] = s1; partials[pidx + 2 * sa.sr_stride] = s2; }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The endpoint pass of the z lines WITHOUT a line solve (single-reduction CG on RT0-P0 slab teams).  What the partition method needs from
+// the first chain solve of an apply are two numbers per z line: c_lo = -x_edge - a_lo u_first and c_hi = x_edge - a_hi u_last, with
+// u = T^-1 t(x).  Both are LINEAR functionals of the line's cell values, c_lo = sum_k W_lo[k] x_k, c_hi = sum_k W_hi[k] x_k, and their weights
+// depend on the factored operator only: the host measures them once per BuildMatrices by sending the unit vector of every plane through the
+// endpoint pass itself (team_endpoint_weights: nz launches per group; |W_lo[k]| decays like 0.268^k away from its interface).  The pass then is
+// a streaming kernel -- the deferred CG update of every cell (r -= alpha q, x += alpha p, p = r + beta p: the same fma expressions as the scan
+// kernel's) and two multiply-adds per cell -- with no scan, no segment summaries and one barrier; on the 2 M-cell slabs of a strong-scaling run,
+// where the scan kernel is latency-bound, that is 41 -> 30 us per launch for the same bytes (72 B per cell: W_lo, W_hi replace L, 1/d).
+// Thread = (x column, one of four z ranges); the four partial sums of a line are added in a fixed order.
+__global__ __launch_bounds__(256) void k_endpoint_w(double *__restrict__ p, double *__restrict__ r, const double *__restrict__ q, double *__restrict__ xsol,
+                                                    const double *__restrict__ Wlo, const double *__restrict__ Whi, double *__restrict__ clo,
+                                                    double *__restrict__ chi, int nx, int ny, int nz, int if_lo, int if_hi, Cg1 sr,
+                                                    const CgScalars *__restrict__ cg, double *__restrict__ rr_part)
+{
+    __shared__ double s_lo[4][64], s_hi[4][64], sred[4];
+    if (cg && cg->done) return;
+    double alpha = 0.0, beta = 0.0;
+    const bool upd = sr.index > 0;
+    if (upd && cg1_step(sr, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, &alpha, &beta)) return;   // every block: the same five doubles, the same decision
+    const int ixl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int ix = blockIdx.x * 64 + ixl;
+    const bool valid = ix < nx;
+    const long nxy = (long)nx * ny, line = (long)blockIdx.y * nx + ix;
+    const int per = (nz + 3) >> 2, k0 = seg * per, k1 = k0 + per < nz ? k0 + per : nz;
+    double a_lo = 0.0, a_hi = 0.0, rr = 0.0;
+    if (valid) {
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const long e = (long)k * nxy + line;
+            double pv = p[e];
+            if (upd) {
+                const double rv = fma(-alpha, q[e], r[e]);           // src/solvers.cpp:610
+                xsol[e] = fma(alpha, pv, xsol[e]);                   // :609
+                pv = fma(beta, pv, rv);                              // :630
+                r[e] = rv; p[e] = pv; rr += rv * rv;
+            } else rr += pv * pv;                                    // first iteration: p = r
+            if (if_lo) a_lo = fma(Wlo[e], pv, a_lo);
+            if (if_hi) a_hi = fma(Whi[e], pv, a_hi);
+        }
+    }
+    s_lo[seg][ixl] = a_lo; s_hi[seg][ixl] = a_hi;
+    __syncthreads();
+    if (seg == 0 && valid) {
+        if (if_lo) clo[line] = ((s_lo[0][ixl] + s_lo[1][ixl]) + s_lo[2][ixl]) + s_lo[3][ixl];
+        if (if_hi) chi[line] = ((s_hi[0][ixl] + s_hi[1][ixl]) + s_hi[2][ixl]) + s_hi[3][ixl];
+    }
+    const double s = block_sum(rr, sred);
+    if (threadIdx.x == 0) rr_part[(long)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
 // ---------------------------------------------------------------------------------------------

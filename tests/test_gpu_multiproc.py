@@ -223,7 +223,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
     assert d1["n_gpus"] == 1 and d1["rccl_ranks"] == 1
-    assert abs(d["keff_after_timed_steps"] - d1["keff_after_timed_steps"]) / d1["keff_after_timed_steps"] < 1e-6
+    # IAEA-3D at the drivers' CG tolerance (1e-4, cond(S) ~ 1e17): the ranks' single-reduction CG and the undivided mesh's reference recurrence end
+    # their solves at different iterates within that tolerance, so k after two unconverged outers agrees to ~4e-6 (measured; two builds of the
+    # ORACLE differ by 1e-6 ... 7e-6 on such runs, tests/golden/rounding_spread.json); the bar is north_star's 1 pcm.  Tight-tolerance agreement of
+    # the same path: test_ranks_on_one_gpu_match_the_undivided_solve (k 1e-8 after 8 fixed outers), test_iaea3d_256cube_golden[c3_layout...] (2e-9).
+    assert abs(d["keff_after_timed_steps"] - d1["keff_after_timed_steps"]) / d1["keff_after_timed_steps"] < 1e-5
 
 
 def test_bench_json_contract_single_rank():

@@ -93,6 +93,30 @@ def test_team_solve_keff_matches_undivided_and_oracle(planes):
     s.close(); t.close()
 
 
+@pytest.mark.parametrize("planes", [[(0, 32), (32, 64), (64, 96)], [(0, 10), (10, 22), (22, 40), (40, 96)]])
+def test_endpoint_pass_as_weighted_sums_matches_the_chain_solve(planes):
+    """The single-reduction CG's endpoint pass without a line solve (k_endpoint_w): c_lo / c_hi of every z line as weighted sums of the
+    line's cells, the weights measured once per BuildMatrices by sending every plane's unit vector through the chain-solve endpoint pass.
+    Same fixed work with the weights on and off (thick slabs, and thin ones with separator sweeps): same k-history to 1e-11, flux to 1e-9,
+    and both against the oracle."""
+    inp = synthetic_inputs(8, 6, 96, 2, seed=9)
+    tol = (0.0, 1e-10, 1e-10, 12, 2000)                            # 12 outers, inner solves converged
+    o = make_oracle(inp); o.set_tol(*tol); ko = o.SolveKeff()
+    res = []
+    for w in (1, 0):
+        t = make_team(inp, planes); t.set_tol(*tol)
+        t.head.set_option("cg_single_reduce", 1); t.head.set_option("endpoint_weights", w)
+        k, n = t.solve_keff()
+        assert n == 12 and t.head.info("cg_reductions") == 1 and t.head.info("endpoint_weights") == w
+        res.append((k, t.history()["k"].copy(), t.get_phi_local().ravel().copy(), t.history()["cg"].sum()))
+        t.close()
+    (k1, h1, p1, c1), (k0, h0, p0, c0) = res
+    np.testing.assert_allclose(h1, h0, rtol=1e-11)
+    assert rel_l2(p1, p0) < 1e-9 and abs(c1 - c0) <= 0.02 * c0
+    np.testing.assert_allclose(h1, o.history()["k"], rtol=1e-9)
+    assert rel_l2(p1, o.phi_dofs().ravel()) < 1e-8
+
+
 def test_team_driver_tolerances_iaea3d_like():
     """reference-driver tolerances on a resampled IAEA-3D core cut into 2 slabs"""
     from neutfem_amd import cases
