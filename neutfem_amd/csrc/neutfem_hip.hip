@@ -1307,7 +1307,7 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     // z passes lose 10 us with it; neutral to -0.5 % at 96^3 ... 192^3)
     sa.xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : (d == 1 && T->opt_nt_loads && S->N > T->nt_min_cells);
     sa.wsmin = T->opt_wsmin;
-    const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 16) * sizeof(double);
+    const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 32) * sizeof(double);   // + reduction scratch (block_sum: 8, block_sum3: 24 doubles at 512 threads)
     const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
     const CgLean lz = (zmode == 1 && S->nloc == 1 && fz.p) ? S->lean_z1 : CgLean{ nullptr, nullptr, 0, 0, 0 };
     // undivided meshes beyond the caches (the classic path's sizes): the variant with streaming loads (SF doubles as that flag for !SLAB)
