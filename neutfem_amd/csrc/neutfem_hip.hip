@@ -1305,9 +1305,9 @@ static int launch_s(nf_solver *S, int d, int g, const ModeArgs &ma, const Geom &
     // XCD-contiguous tile order (k_schur_s): bit 0 = y passes, bit 1 = z passes; -1 (default) = the y passes of meshes in the streaming
     // regime -- the 8 x tiles of a row set then run on one XCD back to back (256^3: y 133 -> 123 us, 501 -> 493 us per CG iteration;
     // z passes lose 10 us with it; neutral to -0.5 % at 96^3 ... 192^3)
-    // slab z passes: the XCD-contiguous order by default too (8-slab loopback at 256^3: accumulation pass 33.3 -> 30.7 us, 848 -> 835 us per CG
-    // iteration, profiles/r04_o_slab_options.txt)
-    sa.xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : ((d == 1 && T->opt_nt_loads && S->N > T->nt_min_cells) || (zmode == 1 || zmode == 2));
+    // z passes of SMALL slabs (at most 6 Mi cells): the XCD-contiguous order by default too (8-slab loopback at 256^3: accumulation pass 33.3 -> 30.7 us,
+    // 848 -> 835 us per CG iteration; 4 slabs 800 -> 773; on 8.4 M / 16.8 M-cell slabs it loses: 93 -> 101 / 191 -> 201 us; profiles/r04_o_slab_options.txt)
+    sa.xcd = T->opt_xcd >= 0 ? (T->opt_xcd >> (d - 1)) & 1 : ((d == 1 && T->opt_nt_loads && S->N > T->nt_min_cells) || ((zmode == 1 || zmode == 2) && S->N <= (6L << 20)));
     sa.wsmin = T->opt_wsmin;
     const size_t lds = (size_t)(4 * TX * (NSEG + 1) + TX + 32) * sizeof(double);   // + reduction scratch (block_sum: 8, block_sum3: 24 doubles at 512 threads)
     const CgFuse fz = (zmode == 1 && S->nloc == 1) ? S->fuse : CgFuse{ nullptr, nullptr, nullptr };
