@@ -1381,7 +1381,7 @@ static int team_endpoint_phase(nf_team *T, int g, const std::vector<const double
             if ((long)gr.x * gr.y <= T->slab_cap) {
                 hipLaunchKernelGGL(k_endpoint_w, gr, dim3(256), 0, T->stream, S->fuse.p, const_cast<double *>(S->fuse.r), (const double *)S->d_q, S->fuse.xsol,
                                    (const double *)(S->d_Wlo + (size_t)g * S->N), (const double *)(S->d_Whi + (size_t)g * S->N), S->d_clo, S->d_chi,
-                                   S->nx, S->ny, S->nz, S->if_lo, S->if_hi, S->cg1, cg, T->d_partials + 3 * T->partial_stride + (long)S->slab_index * T->slab_cap);
+                                   S->nx, S->ny, S->nz, S->if_lo, S->if_hi, 40, S->cg1, cg, T->d_partials + 3 * T->partial_stride + (long)S->slab_index * T->slab_cap);
                 S->sr_cnt3 = (int)(gr.x * gr.y); T->last_endpoint_w = 1;
                 continue;
             }

@@ -93,7 +93,7 @@ def test_team_solve_keff_matches_undivided_and_oracle(planes):
     s.close(); t.close()
 
 
-@pytest.mark.parametrize("planes", [[(0, 32), (32, 64), (64, 96)], [(0, 10), (10, 22), (22, 40), (40, 96)]])
+@pytest.mark.parametrize("planes", [[(0, 32), (32, 64), (64, 96)], [(0, 10), (10, 22), (22, 40), (40, 96)], [(0, 48), (48, 96)]])   # the last: beyond 40 planes from its interface a weight is not read
 def test_endpoint_pass_as_weighted_sums_matches_the_chain_solve(planes):
     """The single-reduction CG's endpoint pass without a line solve (k_endpoint_w): c_lo / c_hi of every z line as weighted sums of the
     line's cells, the weights measured once per BuildMatrices by sending every plane's unit vector through the chain-solve endpoint pass.
