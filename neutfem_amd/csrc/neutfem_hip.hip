@@ -977,7 +977,7 @@ static int team_prepare(nf_team *T)
                 if (S->if_lo) hipLaunchKernelGGL(k_sred_inv, dim3(gr), dim3(256), 0, T->stream, S->d_hlo + g * nl, S->d_rlo, S->d_sinv_lo + g * nl, nl, 0);
                 if (S->if_hi) hipLaunchKernelGGL(k_sred_inv, dim3(gr), dim3(256), 0, T->stream, S->d_hhi + g * nl, S->d_rhi, S->d_sinv_hi + g * nl, nl, 1);
             }
-            HIPCHK(hipStreamSynchronize(T->stream));
+            NFCHK(team_stream_wait(T, T->stream));
         }
         // separators must decouple through a slab: |a_lo a_hi (T_II^-1)[first,last]| * sqrt(sinv_lo sinv_hi) <= 1e-15.
         // The verdict is taken on the maximum over ALL ranks, so that every process of a decomposed run refuses together
@@ -999,7 +999,7 @@ static int team_prepare(nf_team *T)
             HIPCHK(hipMemcpyAsync(T->d_red, &worst, sizeof(double), hipMemcpyHostToDevice, T->stream));
             NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
             HIPCHK(hipMemcpyAsync(&worst, T->d_red, sizeof(double), hipMemcpyDeviceToHost, T->stream));
-            HIPCHK(hipStreamSynchronize(T->stream));
+            NFCHK(team_stream_wait(T, T->stream));                      // a collective sits on the stream: bounded wait (NEUTFEM_COMM_TIMEOUT_S)
         }
         // Jacobi on the separator system contracts by <= 2 * worst per sweep (two neighbours): sweeps until the neglected term is
         // below 1e-16 of the solution; none for thick slabs (>= ~30 planes), refused beyond 8 (slabs of fewer than ~4 planes)
@@ -1035,7 +1035,7 @@ static int team_prepare(nf_team *T)
         HIPCHK(hipMemcpyAsync(T->d_red, v, sizeof v, hipMemcpyHostToDevice, T->stream));
         NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 5, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
         HIPCHK(hipMemcpyAsync(v, T->d_red, sizeof v, hipMemcpyDeviceToHost, T->stream));
-        HIPCHK(hipStreamSynchronize(T->stream));
+        NFCHK(team_stream_wait(T, T->stream));                      // a collective sits on the stream: bounded wait (NEUTFEM_COMM_TIMEOUT_S)
         T->team_max_cells = (long)v[4];                              // every rank takes the same decision about the CG form (cg_solve)
         T->vec_cnt_pq = np; T->vec_cnt_rr = nr;
         T->vec_stride = T->slab_cap + 2;
@@ -1950,7 +1950,7 @@ int nf_build_diagonal_cache(nf_handle S)
             hipLaunchKernelGGL(k_diag_cache, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, T->stream, make_geom(X), X->d_D + g * N, X->d_Cd + g * N,
                                X->d_Sinv + g * N, N, X->if_lo ? X->d_rlo : (const double *)nullptr, X->if_hi ? X->d_rhi : (const double *)nullptr);
         }
-        HIPCHK(hipStreamSynchronize(T->stream));                  // the exchange buffers are reused by the next group
+        NFCHK(team_stream_wait(T, T->stream));                  // the exchange buffers are reused by the next group
     }
     HIPCHK(hipGetLastError());
     for (auto *X : T->slabs) X->diag_valid = true;
@@ -2044,7 +2044,7 @@ static int team_reconstruct_Jz(nf_team *T)
             nf_solver *S = T->slabs[i];
             NFCHK(launch_s(S, 2, g, mode_args(S, g, 2, 0, xs[i], ys[i]), make_geom(S), 0, nullptr, nullptr, nullptr, 3));
         }
-        HIPCHK(hipStreamSynchronize(T->stream));                  // the exchange buffers are reused by the next group
+        NFCHK(team_stream_wait(T, T->stream));                  // the exchange buffers are reused by the next group
     }
     HIPCHK(hipGetLastError());
     for (auto *S : T->slabs) S->jz_valid = true;
@@ -2090,7 +2090,7 @@ static int team_reconstruct_Jz_diag(nf_team *T)
                                S->d_Jz + (size_t)g * S->nJz, nl, S->if_lo, S->if_hi, (const double *)S->d_rlo, (const double *)S->d_ctlo,
                                (const double *)S->d_rhi, (const double *)S->d_cthi);
         }
-        HIPCHK(hipStreamSynchronize(st));                         // the exchange buffers are reused by the next group
+        NFCHK(team_stream_wait(T, st));                         // the exchange buffers are reused by the next group
     }
     HIPCHK(hipGetLastError());
     for (auto *S : T->slabs) S->jz_valid = true;
@@ -2241,7 +2241,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         HIPCHK(hipMemcpyAsync(T->d_red, &bad, sizeof(double), hipMemcpyHostToDevice, T->stream));
         NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_MAX, T->comm, T->stream));
         HIPCHK(hipMemcpyAsync(&bad, T->d_red, sizeof(double), hipMemcpyDeviceToHost, T->stream));
-        HIPCHK(hipStreamSynchronize(T->stream));
+        NFCHK(team_stream_wait(T, T->stream));                      // a collective sits on the stream: bounded wait (NEUTFEM_COMM_TIMEOUT_S)
     }
     if (bad != 0.0) {
         if (ns == 1 && T->nproc == 1) return NF_OK;
@@ -2284,6 +2284,7 @@ static int coarse_init(nf_team *T, const nf_keff_opts *o, double *k_coarse, cons
         }
         if (hipStreamSynchronize(CT->stream) != hipSuccess) rc = fail(NF_ERR_HIP, "prolong failed");
     }
+    if (CT && CT->dead) { T->dead = true; T->comm = nullptr; T->comm_x = nullptr; }   // a collective of the coarse solve timed out on the BORROWED communicator: the fine team lost it too
     if (CT) { CT->comm = nullptr; CT->comm_x = nullptr; CT->nproc = 1; CT->rccl_reduce = false; }   // borrowed for the solve only: never destroyed with the coarse team
     if (rc != NF_OK) { coarse_cache_drop(T); return rc; }
     *k_coarse = kc; *done = true;
@@ -2441,7 +2442,7 @@ static int cmfd_initialize_team(nf_team *T)
                 if (S->if_hi) hipLaunchKernelGGL(k_cmfd_dtilde_iface, dim3(gr), dim3(256), 0, st, (const double *)(S->d_D + (size_t)g * S->N + (size_t)(S->nz - 1) * nl),
                                                  (const double *)S->d_cthi, (const double *)S->d_rhi, S->hz.back(), Dt + (size_t)S->nz * nl, nl, 0);
             }
-            HIPCHK(hipStreamSynchronize(st));                     // the exchange planes are reused by the next group
+            NFCHK(team_stream_wait(T, st));                     // the exchange planes are reused by the next group
         }
         HIPCHK(hipGetLastError());
     }
@@ -3095,7 +3096,7 @@ int nf_solve_adjoint(nf_handle S, const nf_keff_opts *o, int normalize_to_direct
         HIPCHK(hipMemcpyAsync(T->d_red, &ntot, sizeof(double), hipMemcpyHostToDevice, st));
         NCCLCHK(g_rccl.AllReduce(T->d_red, T->d_red, 1, NCCL_DOUBLE, NCCL_SUM, T->comm, st));
         HIPCHK(hipMemcpyAsync(&ntot, T->d_red, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        NFCHK(team_stream_wait(T, st));
     }
     std::vector<DevTmp<double>> nsft(ns);
     std::vector<int> gN(ns), gT(ns);
