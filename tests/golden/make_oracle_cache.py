@@ -20,6 +20,9 @@ def cases():
         out.append((f"paths tight {shape} RT{rt}-P{p} {ng}g", ("synthetic", shape, ng, 7), dict(rt=rt, p=p, tol=test_gpu_paths.TIGHT)))
     for rt, p, shape in test_gpu_orders.ORDER_CASES:
         out.append((f"orders {shape} RT{rt}-P{p}", ("synthetic", shape, 2, 5 + rt + p), dict(rt=rt, p=p, tol=test_gpu_orders.ORDER_TOL, want_J=False)))
+    for shape, _planes in test_gpu_slabs.HO_SHAPES:
+        for rt, p in test_gpu_slabs.HO_ORDERS:
+            out.append((f"team solve {shape} RT{rt}-P{p}", ("synthetic5", shape, 2, rt + 7 * p + shape[2]), dict(rt=rt, p=p, tol=test_gpu_slabs.HO_SOLVE_TOL, want_J=False)))
     out.append(("checkerboard 24^3 x 8 groups", ("checker", 24, 8), dict(rt=0, p=0, tol=test_gpu_more.CHECKER_TOL, coarse=[2, 2, 2], want_J=False)))
     out.append(("team solve 8 x 6 x 96", ("synthetic", (8, 6, 96), 2, 9), dict(rt=0, p=0, tol=test_gpu_slabs.TEAM_TOL, want_J=False)))
     return out
@@ -29,6 +32,8 @@ def build_input(spec):
     from helpers import synthetic_inputs
     if spec[0] == "synthetic":
         return synthetic_inputs(*spec[1], ng=spec[2], seed=spec[3])
+    if spec[0] == "synthetic5":                                  # five Dirichlet sides (the slab tests of the higher orders)
+        return synthetic_inputs(*spec[1], ng=spec[2], seed=spec[3], dirichlet=(1, 2, 3, 5, 6))
     import test_gpu_more
     from neutfem_amd import cases as gen
     return test_gpu_more._from_case(gen.synthetic_checkerboard(spec[1], spec[2]))

@@ -210,14 +210,20 @@ def test_team_currents_match_oracle(planes):
     t.close()
 
 
-@pytest.mark.parametrize("rt,p", [(1, 1), (1, 0), (2, 2), (2, 1)])
-@pytest.mark.parametrize("shape,planes", [((5, 4, 20), [(0, 9), (9, 20)]), ((4, 3, 30), [(0, 10), (10, 20), (20, 30)])])
+HO_ORDERS = [(1, 1), (1, 0), (2, 2), (2, 1)]
+HO_SHAPES = [((5, 4, 20), [(0, 9), (9, 20)]), ((4, 3, 30), [(0, 10), (10, 20), (20, 30)])]
+HO_CURRENT_TOL = (1e-12, 1e-11, 1e-11, 12, 3000)
+HO_SOLVE_TOL = (1e-12, 1e-10, 1e-10, 10, 3000)
+
+
+@pytest.mark.parametrize("rt,p", HO_ORDERS)
+@pytest.mark.parametrize("shape,planes", HO_SHAPES)
 def test_team_currents_higher_orders(shape, planes, rt, p):
     """Sol_J_ of RT1 / RT2 on slabs: the partition-method solve in emit mode stores, per transverse mode, the face DOFs of every local
     z face (separators included) and the z bubbles of every local cell (edge cells included); x / y DOFs are slab-local"""
     inp = synthetic_inputs(*shape, ng=2, seed=21 + rt, dirichlet=(1, 2, 3, 5, 6))
     o, t = make_oracle(inp, rt, p), make_team_order(inp, planes, rt, p)
-    tol = (1e-12, 1e-11, 1e-11, 12, 3000)                          # fixed work: 12 outers, tight inner solves
+    tol = HO_CURRENT_TOL                                          # fixed work: 12 outers, tight inner solves
     o.set_tol(*tol); t.set_tol(*tol)
     ko = o.SolveKeff(); kt, _ = t.solve_keff()
     assert abs(kt - ko) / ko < 1e-9
@@ -244,8 +250,8 @@ def _team_vector(t, nz, ny, nx, nloc, v):
     return v.reshape(nz, ny * nx * nloc)
 
 
-@pytest.mark.parametrize("rt,p", [(1, 1), (1, 0), (2, 2), (2, 1)])
-@pytest.mark.parametrize("shape,planes", [((5, 4, 20), [(0, 9), (9, 20)]), ((4, 3, 30), [(0, 10), (10, 20), (20, 30)])])
+@pytest.mark.parametrize("rt,p", HO_ORDERS)
+@pytest.mark.parametrize("shape,planes", HO_SHAPES)
 def test_team_higher_orders_match_oracle(shape, planes, rt, p):
     """RT1 / RT2 on slab teams: every transverse mode has its own separator planes (same unit-scaled factors), the edge cells
     contribute xL / xR and receive their bubble moments; apply and power iteration against the undivided oracle"""
@@ -266,12 +272,12 @@ def test_team_higher_orders_match_oracle(shape, planes, rt, p):
     y = np.concatenate([s._from_dev(v.download()) for s, v in zip(t.slabs, yd)])
     assert rel_l2(y, o.schur_apply(1, x)) < 1e-12
     for v in xd + yd: v.free()
-    tol = (1e-12, 1e-10, 1e-10, 10, 3000)                          # fixed work
-    o.set_tol(*tol); t.set_tol(*tol)
-    ko = o.SolveKeff(); kt, n = t.solve_keff()
-    assert n == 10 and abs(kt - ko) / ko < 1e-9
+    tol = HO_SOLVE_TOL                                             # fixed work
+    so = solved_oracle(inp, rt, p, tol, want_J=False); t.set_tol(*tol)   # the oracle's ten outers: committed (helpers.solved_oracle)
+    ko = so.k; kt, n = t.solve_keff()
+    assert n == 10 == so.n_outer and abs(kt - ko) / ko < 1e-9
     phi = np.concatenate([s.get_phi().reshape(2, -1) for s in t.slabs], axis=1)
-    assert rel_l2(phi.ravel(), o.phi_dofs().ravel()) < 1e-8
+    assert rel_l2(phi.ravel(), so.phi_dofs().ravel()) < 1e-8
     t.close()
 
 

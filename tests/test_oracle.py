@@ -357,7 +357,7 @@ def test_oracle_cache_is_current():
     spec = importlib.util.spec_from_file_location("make_oracle_cache", os.path.join(os.path.dirname(__file__), "golden", "make_oracle_cache.py"))
     gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
     cases = gen.cases()
-    assert len(cases) == 23
+    assert len(cases) == 31
     live = 0
     for label, inp_spec, kw in cases:
         inp = gen.build_input(inp_spec)
