@@ -3,8 +3,9 @@ oracle's Schur operator, before any GPU is involved (VERDICT r3 item 1 proposed 
 
 IAEA-3D fills its blank assemblies with Sigma = 1e15, D = 1e-3 (tests/iaea3d/iaea3d.py:254): cond(S) ~ 1e17 and |r|^2 swings by ten
 orders of magnitude between consecutive iterations of the reference's unpreconditioned CG.  On that operator
-  * Chronopoulos-Gear (p.Sp from r.Sr and the previous scalars) and the two-term prediction |r_new|^2 = alpha^2 q.q - |r|^2 (which
-    assumes r_new . r = 0) NEVER converge;
+  * Chronopoulos-Gear (p.Sp from r.Sr and the previous scalars), its pipelined form (Ghysels-Vanroose: the same scalars plus recurrences
+    for S p and S S p, which is what would let the reduction run under the next apply -- item 1b) and the two-term prediction
+    |r_new|^2 = alpha^2 q.q - |r|^2 (which assumes r_new . r = 0) NEVER converge;
   * the form the device runs (Cg1 in nf_kernels.h: one reduction carrying p.q, q.q, r.q and the MEASURED |r|^2; the predicted
     |r_new|^2 = |r|^2 - 2 alpha r.q + alpha^2 q.q feeds beta only; stop test on measured values, one apply late) converges with the
     reference's iteration counts to within a few per cent and to the same solution within the spread that two builds of the
@@ -35,6 +36,21 @@ def chronopoulos_gear(S, b, tol, maxit):
         s = S(r); gn = r @ r; d = r @ s
         if gn < t2: return x, it + 1
         beta = gn / g; a = gn / (d - beta * gn / a); g = gn
+    return x, maxit
+
+
+def pipelined(S, b, tol, maxit):
+    """Ghysels-Vanroose pipelined CG: Chronopoulos-Gear's scalars plus recurrences for s = S p and z = S s, so that the one reduction of an
+    iteration can run under the next apply"""
+    x = np.zeros_like(b); r = b.copy(); w = S(r); t2 = tol * tol * (b @ b)
+    p = np.zeros_like(b); s = np.zeros_like(b); z = np.zeros_like(b); g0 = a = 1.0
+    for it in range(maxit):
+        g = r @ r; d = w @ r; q = S(w)                           # the reduction of (g, d) is what the apply S(w) would hide
+        if g < t2: return x, it
+        beta = g / g0 if it else 0.0
+        a = g / (d - beta * g / a) if it else g / d
+        z = q + beta * z; s = w + beta * s; p = r + beta * p
+        x += a * p; r -= a * s; w -= a * z; g0 = g
     return x, maxit
 
 
@@ -75,7 +91,7 @@ def test_recurrence_variants_fail_on_iaea3d_and_the_device_form_does_not(g):
     x0, n0 = std_cg(S, b, 1e-4, 1000)
     assert n0 < 60 and res(x0) < 1.01e-4
     # the proposed single-reduction recurrences: 400 iterations (ten times the reference's count) and nowhere near
-    for f in (chronopoulos_gear, two_term):
+    for f in (chronopoulos_gear, two_term, pipelined):
         x, n = f(S, b, 1e-4, 400)
         assert n == 400 or res(x) > 1e-2, (f.__name__, n, res(x))
     # the device's form: the drivers' tolerance ...
@@ -94,11 +110,23 @@ def test_all_variants_agree_on_the_well_conditioned_benchmarks(name, ng):
         o, S, b = _problem(name, g)
         for tol in (1e-4, 1e-10):
             x0, n0 = std_cg(S, b, tol, 2000)
-            for f in (device_form, chronopoulos_gear, two_term):
+            for f in (device_form, chronopoulos_gear, two_term) + ((pipelined,) if name != "koeberg2d" else ()):
                 x, n = f(S, b, tol, 2000)
                 assert n == n0, (name, g, tol, f.__name__, n, n0)
                 bar = (1e-9 if tol > 1e-6 else 1e-12) if f is device_form else 1e-6       # the recurrence variants drift first (KOEBERG: 2e-9 at 28 iterations)
                 assert np.linalg.norm(x - x0) / np.linalg.norm(x0) < bar, (name, g, tol, f.__name__)
+
+
+def test_pipelined_form_loses_koeberg_too():
+    """VERDICT r3 item 1b (hide the all-reduce under the next apply) needs S p and S S p by recurrence.  KOEBERG's fast group already breaks that: |r|^2
+    swings by seven orders of magnitude between iterations there, the recurred w = S r drifts to 1e-3 relative within 35 iterations and the true residual
+    stalls where the reference's recurrence is done after 28 iterations."""
+    o, S, b = _problem("koeberg2d", 0)
+    x0, n0 = std_cg(S, b, 1e-4, 2000)
+    x, n = pipelined(S, b, 1e-4, 20 * n0)
+    assert n0 < 40 and (n == 20 * n0 or np.linalg.norm(b - S(x)) / np.linalg.norm(b) > 1e-3), (n0, n)
+    x1, n1 = device_form(S, b, 1e-4, 2000)
+    assert n1 == n0
 
 
 def test_device_form_honours_maxit_and_zero_rhs():
