@@ -49,10 +49,10 @@ def test_thin_slabs_use_separator_sweeps(planes):
     for g in range(2):
         x = rng.standard_normal((30, 8, 9))
         assert rel_l2(t.schur_apply(g, x).ravel(), o.schur_apply(g, x.ravel())) < 1e-12
-    tol = (1e-12, 1e-10, 1e-10, 20, 2000)                          # fixed work: 20 outers with tight inner solves
+    tol = (1e-12, 1e-10, 1e-10, 10, 2000)                          # fixed work: 10 outers with tight inner solves
     o.set_tol(*tol); t.set_tol(*tol)
     ko = o.SolveKeff(); kt, n = t.solve_keff()
-    assert n == o.info("last_outer") == 20 and abs(kt - ko) / ko < 1e-9
+    assert n == o.info("last_outer") == 10 and abs(kt - ko) / ko < 1e-9
     assert rel_l2(t.get_phi_local().ravel(), o.phi_dofs().reshape(2, 30, 8, 9).ravel()) < 1e-8
     t.close()
 
@@ -198,7 +198,7 @@ def test_team_currents_match_oracle(planes):
     nz = planes[-1][1]
     inp = synthetic_inputs(8, 6, nz, 2, seed=13, dirichlet=(1, 2, 4, 5, 6))
     o, t = make_oracle(inp), make_team(inp, planes)
-    tol = (1e-12, 1e-11, 1e-11, 30, 3000)                          # fixed work: 30 outers, tight inner solves
+    tol = (1e-12, 1e-11, 1e-11, 12, 3000)                          # fixed work: 12 outers, tight inner solves
     o.set_tol(*tol); t.set_tol(*tol)
     ko = o.SolveKeff(); kt, _ = t.solve_keff()
     assert abs(kt - ko) / ko < 1e-9
@@ -212,7 +212,8 @@ def test_team_currents_match_oracle(planes):
 
 HO_ORDERS = [(1, 1), (1, 0), (2, 2), (2, 1)]
 HO_SHAPES = [((5, 4, 20), [(0, 9), (9, 20)]), ((4, 3, 30), [(0, 10), (10, 20), (20, 30)])]
-HO_CURRENT_TOL = (1e-12, 1e-11, 1e-11, 12, 3000)
+HO_CURRENT_TOL = (1e-12, 1e-11, 1e-11, 5, 3000)      # five outers: the oracle's RT2-P2 solve is what this test waits for (12 outers: 12 s per case), and the
+                                                      # currents of a fixed amount of work are as comparable after 5 outers as after 12
 HO_SOLVE_TOL = (1e-12, 1e-10, 1e-10, 10, 3000)
 
 
@@ -223,7 +224,7 @@ def test_team_currents_higher_orders(shape, planes, rt, p):
     z face (separators included) and the z bubbles of every local cell (edge cells included); x / y DOFs are slab-local"""
     inp = synthetic_inputs(*shape, ng=2, seed=21 + rt, dirichlet=(1, 2, 3, 5, 6))
     o, t = make_oracle(inp, rt, p), make_team_order(inp, planes, rt, p)
-    tol = HO_CURRENT_TOL                                          # fixed work: 12 outers, tight inner solves
+    tol = HO_CURRENT_TOL                                          # fixed work: 5 outers, tight inner solves
     o.set_tol(*tol); t.set_tol(*tol)
     ko = o.SolveKeff(); kt, _ = t.solve_keff()
     assert abs(kt - ko) / ko < 1e-9
