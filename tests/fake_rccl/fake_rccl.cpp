@@ -7,6 +7,11 @@
 // function that talks to the other ranks through a POSIX shared-memory segment, staging -> device copy).  Sends are
 // buffered in a one-message mailbox per ordered rank pair, so the send/recv order of neutfem_hip's grouped exchange
 // cannot deadlock; all-reduces sum in rank order on every rank (bitwise identical results everywhere, like RCCL).
+// Operations on ONE communicator are serialized in the order of the calls, whatever streams they are given (an event chain per
+// communicator: a call on another stream than its predecessor's first waits for the predecessor) -- that is what RCCL does (every launch of
+// a communicator goes through the communicator's own device stream), and it turns a schedule whose stream dependencies contradict the
+// order of the calls into a hang here as it would be there.  FAKE_RCCL_SERIALIZE=0 switches the chain off; FAKE_RCCL_REPORT=1 prints the
+// number of calls and of cross-stream waits per rank when the communicator is destroyed.
 // Only what neutfem_hip needs: fp64, sum / max, counts <= 20480 for all-reduce (scalars and the vectors of block partials), nranks <= 8.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
@@ -34,7 +39,22 @@ struct Comm {
     Shared *sh; double *data; char name[80];
     long ar_seq = 0, send_seq[MAXR] = {0}, recv_seq[MAXR] = {0};
     double *stage_ar = nullptr, *stage_send[MAXR] = {nullptr}, *stage_recv[MAXR] = {nullptr};
+    bool serialize = true, have_last = false; hipEvent_t ev = nullptr; hipStream_t last = nullptr; long calls = 0, cross = 0;
 };
+// the communicator's chain: the call waits for its predecessor if that one went to another stream, and becomes the predecessor
+bool chain_begin(Comm *c, hipStream_t st)
+{
+    ++c->calls;
+    if (!c->serialize || !c->have_last || c->last == st) return true;
+    ++c->cross;
+    return hipStreamWaitEvent(st, c->ev, 0) == hipSuccess;
+}
+bool chain_end(Comm *c, hipStream_t st)
+{
+    if (!c->serialize) return true;
+    c->have_last = true; c->last = st;
+    return hipEventRecord(c->ev, st) == hipSuccess;
+}
 double *box_data(Comm *c, int src, int dst) { return c->data + ((size_t)src * MAXR + dst) * c->cap; }
 bool wait_until(const std::atomic<long> &a, long v)
 {
@@ -116,6 +136,8 @@ int ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank)
         if (hipHostMalloc((void **)&c->stage_send[r], c->cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
         if (hipHostMalloc((void **)&c->stage_recv[r], c->cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
     }
+    const char *se = getenv("FAKE_RCCL_SERIALIZE"); c->serialize = !(se && atoi(se) == 0);
+    if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) return 1;
     c->sh->joined.fetch_add(1);
     const time_t t0 = time(nullptr);
     while (c->sh->joined.load() < nranks) { if (time(nullptr) - t0 > 120) return 1; usleep(100); }
@@ -126,6 +148,8 @@ int ncclCommDestroy(ncclComm_t c)
 {
     if (!c) return 0;
     (void)hipDeviceSynchronize();
+    if (getenv("FAKE_RCCL_REPORT")) fprintf(stderr, "fake_rccl: rank %d of %d: %ld calls, %ld cross-stream waits\n", c->rank, c->nranks, c->calls, c->cross);
+    (void)hipEventDestroy(c->ev);
     for (int r = 0; r < c->nranks; ++r) { (void)hipHostFree(c->stage_send[r]); (void)hipHostFree(c->stage_recv[r]); }
     (void)hipHostFree(c->stage_ar);
     munmap((void *)c->sh, c->bytes);
@@ -139,20 +163,26 @@ int ncclGroupEnd() { return 0; }
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t st)
 {
     if (dtype != 8 || (op != 0 && op != 2) || count > (size_t)AR_MAX) return 1;               // ncclSum / ncclMax
+    if (!chain_begin(c, st)) return 1;
     if (hipMemcpyAsync(c->stage_ar, send, count * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
     if (hipLaunchHostFunc(st, cb_allreduce, new Op{ c, -1, count, ++c->ar_seq, op }) != hipSuccess) return 1;
-    return hipMemcpyAsync(recv, c->stage_ar, count * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : 1;
+    if (hipMemcpyAsync(recv, c->stage_ar, count * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    return chain_end(c, st) ? 0 : 1;
 }
 int ncclSend(const void *buf, size_t count, int dtype, int peer, ncclComm_t c, hipStream_t st)
 {
     if (dtype != 8 || (long)count > c->cap || peer < 0 || peer >= c->nranks) return 1;
+    if (!chain_begin(c, st)) return 1;
     if (hipMemcpyAsync(c->stage_send[peer], buf, count * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
-    return hipLaunchHostFunc(st, cb_send, new Op{ c, peer, count, ++c->send_seq[peer], 0 }) == hipSuccess ? 0 : 1;
+    if (hipLaunchHostFunc(st, cb_send, new Op{ c, peer, count, ++c->send_seq[peer], 0 }) != hipSuccess) return 1;
+    return chain_end(c, st) ? 0 : 1;
 }
 int ncclRecv(void *buf, size_t count, int dtype, int peer, ncclComm_t c, hipStream_t st)
 {
     if (dtype != 8 || (long)count > c->cap || peer < 0 || peer >= c->nranks) return 1;
+    if (!chain_begin(c, st)) return 1;
     if (hipLaunchHostFunc(st, cb_recv, new Op{ c, peer, count, ++c->recv_seq[peer], 0 }) != hipSuccess) return 1;
-    return hipMemcpyAsync(buf, c->stage_recv[peer], count * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : 1;
+    if (hipMemcpyAsync(buf, c->stage_recv[peer], count * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    return chain_end(c, st) ? 0 : 1;
 }
 }

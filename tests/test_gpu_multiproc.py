@@ -206,7 +206,7 @@ def test_every_rank_issues_the_same_sequence_of_collectives(tmp_path, cg1):
     NEUTFEM_TRACE_COMM=1 every rank prints one line per collective it enqueues (plane exchanges, all-reduces, verdicts); the three ranks of a solve
     -- coarse twin, thin slabs with separator sweeps, currents at the end -- must print the SAME sequence of (kind, element count), whatever their
     position in the stack (the bottom and top ranks have one neighbour, the middle one two: same calls, other peers).  Both CG routes."""
-    e = _env(); e["NEUTFEM_TRACE_COMM"] = "1"; e["NEUTFEM_TEST_CG1"] = cg1
+    e = _env(); e["NEUTFEM_TRACE_COMM"] = "1"; e["NEUTFEM_TEST_CG1"] = cg1; e["FAKE_RCCL_REPORT"] = "1"
     e["NEUTFEM_TEST_VEC_REDUCE"] = "0"                              # the reference recurrence through k_finalize + scalar all-reduces (the vector all-reduce is not traced)
     out = str(tmp_path / "res.npz")
     bad, logs = _run_ranks(3, [out, 1, 0, 16, 0, 0, 4], tmp_path, env=e)
@@ -229,6 +229,12 @@ def test_every_rank_issues_the_same_sequence_of_collectives(tmp_path, cg1):
                 else:
                     seq.append(("other", body.split()[0], ""))
             seqs.append(seq)
+    # the stand-in serializes the calls on one communicator like RCCL does (an all-reduce on the solver's stream waits for the exchange issued before it on
+    # the comm stream, and the other way round): the run above went through that chain -- thousands of cross-stream waits per rank -- without hanging
+    import re
+    logs_all = "".join(open(str(tmp_path / f"rank{r}.log")).read() for r in range(3))
+    waits = [int(m.group(1)) for m in re.finditer(r"fake_rccl: rank \d of 3: \d+ calls, (\d+) cross-stream waits", logs_all)]
+    assert len(waits) >= 3 and min(waits) > 500, (waits, logs_all[-500:])
     assert len(seqs[0]) > 200, len(seqs[0])                        # exchanges and reductions of two group solves per outer, coarse and fine
     assert seqs[0] == seqs[1] == seqs[2], next((i, a, b, c) for i, (a, b, c) in enumerate(zip(*seqs)) if not (a == b == c)) if len(set(map(len, seqs))) == 1 else list(map(len, seqs))
     n_ar = sum(1 for t in seqs[0] if t[0] == "allreduce" and t[1] in ("single-reduction", "reduce")); n_x = sum(1 for t in seqs[0] if t[0] == "exchange" and t[1] == "0")
