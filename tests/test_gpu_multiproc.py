@@ -64,7 +64,7 @@ def _run_ranks(world, args, tmp_path, timeout=200, env=None, wait_all=False):
 def test_ranks_on_one_gpu_match_the_undivided_solve(world, per, use_diag, planes, tmp_path):
     """planes = 48: coarse slabs of 24 planes need one separator sweep; planes = 12: the fine slabs themselves are thin"""
     out = str(tmp_path / "res.npz")
-    NO = 8 if use_diag == 0 else 16                                # fixed work: outers of the fine solve (the full path spends half as many on the coarse twin first)
+    NO = (4 if world == 4 else 8) if use_diag == 0 else 16         # fixed work: outers of the fine solve (the full path spends half as many on the coarse twin first; four ranks of thin slabs: 8 sweeps per apply)
     bad, logs = _run_ranks(world, [out, per, use_diag, planes, 0, 0, NO], tmp_path)
     assert bad is None, bad + "\n" + logs
     res = np.load(out)
@@ -94,7 +94,7 @@ def test_reduction_routes_agree(tmp_path):
     for cg1, vec, xc in (("1", "1", "1"), ("0", "1", "0"), ("0", "0", "0")):
         e = _env(); e["NEUTFEM_TEST_CG1"] = cg1; e["NEUTFEM_TEST_VEC_REDUCE"] = vec; e["NEUTFEM_TEST_XCHG_COMM"] = xc
         out = str(tmp_path / f"res{cg1}{vec}.npz")
-        bad, logs = _run_ranks(3, [out, 1, 0, 16, 0, 0, 6], tmp_path, env=e)   # 6 fine outers (3 coarse), thin slabs: one separator sweep per apply
+        bad, logs = _run_ranks(3, [out, 1, 0, 16, 0, 0, 4], tmp_path, env=e)   # 4 fine outers (2 coarse), thin slabs: one separator sweep per apply
         assert bad is None, bad + "\n" + logs
         outs.append(np.load(out))
     a, b, c = outs
