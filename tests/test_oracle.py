@@ -318,7 +318,7 @@ def test_iaea3d_as_specified_approaches_the_literature_k():
     -- and keeps the reference's boundary term on the box; the benchmark has the vacuum condition J.n = 0.4692 phi on the stepped outline and on top and
     bottom.  With the blanks cut out and that condition in their place (nfo_set_void; oracle/iaea3d_as_specified.py, table in
     tests/golden/iaea3d_as_specified.json) every order climbs onto the literature value from below -- RT0-P0 -87 / -68 / -30 pcm at 1 / 2 / 4 cells per
-    assembly, RT1-P1 -55 / -13 / **-2.8**, RT2-P2 -14 / **-2.1** -- while the driver's variant overshoots it (RT1-P1: -39, +7).  The literature scalar pins the
+    assembly, RT1-P1 -55 / -13 / **-2.8**, RT2-P2 -14 / **-2.1** -- while the driver's variant overshoots it (RT1-P1: -39, +7; RT2-P2 on the assembly mesh: +5.6).  The literature scalar pins the
     oracle on IAEA-3D to about 2 pcm (RT2-P2 at 2 x 2 x 2 and RT1-P1 at 4 x 4 x 4: 1.6 and 2 hours of one core, committed; the cheap entries are recomputed here;
     Richardson on RT1-P1's three values -- differences 42.6 and 9.8 -- puts its limit at +0.2 pcm)."""
     import importlib.util, json, os
@@ -336,6 +336,7 @@ def test_iaea3d_as_specified_approaches_the_literature_k():
     d1, d2 = pcm("spec", 1, 2) - pcm("spec", 1, 1), pcm("spec", 1, 4) - pcm("spec", 1, 2)
     assert abs(pcm("spec", 1, 4) + d2 / (d1 / d2 - 1.0)) < 1.0                # Richardson limit of RT1-P1: within 1 pcm of k_ref
     assert pcm("driver", 1, 2) > 5.0 > 0 > pcm("spec", 1, 2)        # the driver's variant is a different problem: it passes the scalar by
+    assert pcm("driver", 2, 1) > 5.0 > 0 > pcm("spec", 2, 1)        # ... at RT2-P2 already on the assembly mesh (+5.6 against -14.0; 184 k CG iterations: the F6 cells' 1e15)
 
 
 def test_readme_result_table_is_not_reproducible():
